@@ -1,0 +1,16 @@
+# Build the HIP engine (gfx950 only) in-tree.  `make` == what __graft_entry__.build() runs.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := pclsegmentation_amd/csrc
+LIB   := pclsegmentation_amd/libpclseg.so
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(LIB): $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
+	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/pclseg_api.hip
+
+clean:
+	rm -f $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: LiDAR scans/s of the forward pass on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = pclseg_forward_raw over one batch of synthetic raw scans already resident in HBM
+(normalise+mask -> network -> argmax -> masked int32 predictions, also left in HBM).  Default
+workload = BASELINE.json configs[1]: SqueezeSegV2, 64x2048, 20 classes, batch 32 per GPU, random
+(seeded) weights of that architecture.  Multi-GPU = weak scaling: every rank runs its own 32-scan
+batch, weights broadcast once over RCCL, no collective inside the timed region.
+
+Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak (= f32 vector peak)
+
+WORKLOADS = {
+  # name: (model, config, H, W, batch per GPU, valid-pixel rate, roofline bound)
+  "ssv2_64x2048": ("squeezesegv2", "squeezesegv2kitti", 64, 2048, 32, 0.78, "hbm"),
+  "darknet53_64x2048": ("darknet53", "darknet53kitti", 64, 2048, 16, 0.78, "mfma"),
+  "darknet21_32x1024": ("darknet21", "darknet21", 32, 1024, 64, 0.59, "mfma"),
+  "ssv2_32x240": ("squeezesegv2", "squeezesegv2", 32, 240, 32, 0.84, "hbm"),
+}
+
+
+def cpu_baseline(model_name, mc, weights, h, w, pvalid, budget_s):
+  """Time the CPU stand-in for the reference's TF2-CPU path on this box's host cores:
+  oracle/torch_ref.py (PyTorch-CPU/oneDNN expression of the identical graph, identical weights).
+  Bounded sample: scans are added until ~budget_s of CPU work has been spent."""
+  import torch
+  from oracle import np_oracle as O
+  from oracle.torch_ref import TorchNet
+  from pclsegmentation_amd.utils.synthetic import synthetic_scans
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  net = TorchNet(model_name, weights, num_layers=mc.get("NUM_LAYERS"),
+                 output_stride=mc.get("OUTPUT_STRIDE", 16))
+  raw = synthetic_scans(2, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid, seed=77)
+  none_index = mc.CLASSES.index("None")
+
+  def one_batch():
+    lidar, mask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+    net(lidar.astype(np.float32), mask, none_index)
+
+  one_batch()  # warm-up (oneDNN primitive creation)
+  done, t0 = 0, time.perf_counter()
+  while True:
+    one_batch()
+    done += raw.shape[0]
+    el = time.perf_counter() - t0
+    if el >= budget_s or done >= 64:
+      break
+  return {"value": round(done / el, 3), "unit": "scans/s", "cores": cores, "kind": "port",
+          "sample": "%d synthetic %dx%d scans, batch 2, PyTorch-CPU (oneDNN) expression of the same "
+                    "graph and weights (oracle/torch_ref.py); TF2 itself is not installable here"
+                    % (done, h, w)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--workload", default="ssv2_64x2048", choices=sorted(WORKLOADS))
+  ap.add_argument("--batch", type=int, default=0, help="scans per GPU per step (0 = workload default)")
+  ap.add_argument("--micro-batch", type=int, default=0)
+  ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
+  args = ap.parse_args()
+
+  import torch
+  import pclsegmentation_amd as P
+  from pclsegmentation_amd import distributed as D
+  from pclsegmentation_amd import engine as E
+  from pclsegmentation_amd.nets.weights import synthetic_weights
+  from pclsegmentation_amd.utils.synthetic import synthetic_scans
+
+  rank, local_rank, world = D.init_process_group()
+  if world != args.gpus:
+    raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+
+  model_name, config_name, h, w, batch, pvalid, bound = WORKLOADS[args.workload]
+  if args.batch:
+    batch = args.batch
+  mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=local_rank,
+                                  micro_batch=args.micro_batch)
+  spec = model.weight_spec()
+  weights = synthetic_weights(spec, 4321) if rank == 0 else None
+  weights = D.broadcast_weights(spec, weights, src=0, device=dev)   # one RCCL broadcast over xGMI
+  model.set_weights(weights)
+  eng = model.engine(h, w)
+  stream = torch.cuda.current_stream(dev)
+  eng.set_stream(stream.cuda_stream)
+  info = E.plan(eng.desc)
+
+  scans = torch.from_numpy(synthetic_scans(batch, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid,
+                                           seed=1234 + rank)).to(dev)
+  preds = torch.empty((batch, h, w), dtype=torch.int32, device=dev)
+
+  def step():
+    eng.forward_raw(scans, batch, preds, None, None, None, mem=E.MEM_DEVICE)
+
+  def fence():
+    torch.cuda.synchronize(dev)
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+
+  for _ in range(args.warmup):
+    step()
+  fence()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record(stream)
+  for _ in range(args.steps):
+    step()
+  ev1.record(stream)
+  fence()
+  elapsed = time.perf_counter() - t0
+  dev_ms = ev0.elapsed_time(ev1)      # HIP events on the engine's stream
+  if world > 1:
+    t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed, dev_ms = float(t[0]), float(t[1])
+
+  if rank == 0:
+    scans_per_s = world * batch * args.steps / elapsed
+    alg_bytes = info["alg_bytes_per_scan"]
+    alg_flops = 2 * info["alg_macs_per_scan"]
+    # roofline over the kernels of one step, per GPU, from the HIP-event time
+    dev_scans_per_s = batch * args.steps / (dev_ms * 1e-3)
+    hbm_gbs = dev_scans_per_s * alg_bytes / 1e9
+    mfma_tf = dev_scans_per_s * alg_flops / 1e12
+    if bound == "hbm":
+      roof = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None}
+    else:
+      roof = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": F32_MFMA_PEAK_TF,
+              "unit": "TFLOP/s", "frac": round(mfma_tf / F32_MFMA_PEAK_TF, 4), "traffic": None}
+    roof["kernel"] = "all kernels of one forward step (HIP events on the engine stream)"
+    roof["alg_bytes_per_scan"] = alg_bytes
+    roof["alg_flops_per_scan"] = alg_flops
+    roof["other"] = {"hbm_GBs": round(hbm_gbs, 1), "f32_mfma_TFLOPs": round(mfma_tf, 2),
+                     "f32_mfma_frac": round(mfma_tf / F32_MFMA_PEAK_TF, 4)}
+    out = {
+      "metric": "LiDAR scans/sec (64x2048) SqueezeSegV2 inference" if args.workload == "ssv2_64x2048"
+                else "LiDAR scans/sec %s inference" % args.workload,
+      "value": round(scans_per_s, 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+      "data": "synthetic",
+      "config": {"workload": args.workload, "model": model_name, "shape": [h, w],
+                 "num_class": mc.NUM_CLASS, "batch_per_gpu": batch, "global_batch": batch * world,
+                 "micro_batch": info["micro_batch"], "parallelism": "batch-sharded x%d" % world},
+      "roofline": roof,
+    }
+    if world == 1 and args.cpu_seconds > 0:
+      out["cpu_baseline"] = cpu_baseline(model_name, mc, weights, h, w, pvalid, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,189 @@
+/*
+ * pclseg.h — C ABI of the MI355X-native forward-pass engine (libpclseg.so).
+ *
+ * The reference has no FFI layer: its operator API for this path is the Keras call
+ *     probabilities, predictions = model([lidar, mask])
+ * (reference: pcl_segmentation/inference.py:75, eval.py:47, utils/callbacks.py:53) on a
+ * model built by load_model_config (utils/args_loader.py:52-55) or loaded with
+ * tf.keras.models.load_model (inference.py:39).  The entry points below are what a
+ * ctypes binding for that call needs; each cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - Every function returns int: 0 = PCLSEG_OK, negative = pclseg_status.  The text of the
+ *     last failure is available from pclseg_last_error().
+ *   - The caller owns every buffer it passes.  `mem` says where the caller's buffers live:
+ *     PCLSEG_MEM_HOST (the library copies over PCIe itself) or PCLSEG_MEM_DEVICE (pointers
+ *     are HIP device pointers on the handle's device; nothing is copied).
+ *   - One handle = one device + one stream; a handle is not thread-safe, independent
+ *     handles are.  Forward calls are asynchronous on the handle's stream in
+ *     PCLSEG_MEM_DEVICE mode (call pclseg_sync or synchronise the stream) and synchronous on
+ *     return in PCLSEG_MEM_HOST mode.
+ *   - All activations are float32 NHWC; predictions are int32.
+ */
+#ifndef PCLSEG_H_
+#define PCLSEG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCLSEG_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef struct pclseg_handle pclseg_handle;
+
+typedef enum pclseg_status {
+  PCLSEG_OK = 0,
+  PCLSEG_ERR_BAD_ARG = -1,        /* null pointer, unknown enum, n <= 0 ...                */
+  PCLSEG_ERR_BAD_SHAPE = -2,      /* W % 16 != 0, tensor shape mismatch (Keras: ValueError) */
+  PCLSEG_ERR_MISSING_WEIGHT = -3, /* finalize with an unset tensor / unknown Keras path    */
+  PCLSEG_ERR_HIP = -4,            /* HIP runtime error (incl. "no GPU")                     */
+  PCLSEG_ERR_OOM = -5,
+  PCLSEG_ERR_STATE = -6           /* forward before finalize, set_weight after finalize     */
+} pclseg_status;
+
+/* model_map keys of the reference (utils/args_loader.py:36-40); darknet21/53 differ only in
+ * NUM_LAYERS (nets/Darknet.py:142-145). */
+typedef enum pclseg_arch {
+  PCLSEG_ARCH_SQUEEZESEGV2 = 0,
+  PCLSEG_ARCH_DARKNET21 = 1,
+  PCLSEG_ARCH_DARKNET53 = 2
+} pclseg_arch;
+
+typedef enum pclseg_mem { PCLSEG_MEM_HOST = 0, PCLSEG_MEM_DEVICE = 1 } pclseg_mem;
+
+/* desc.flags */
+#define PCLSEG_FLAG_KEEP_ACTIVATIONS 1u /* debug: no workspace aliasing, so every
+                                           intermediate can be read back after a forward */
+
+/* Everything the forward pass reads from a reference config (configs/ *.py: ZENITH_LEVEL,
+ * AZIMUTH_LEVEL, NUM_CLASS, CLASSES.index("None"), INPUT_MEAN, INPUT_STD, OUTPUT_STRIDE). */
+typedef struct pclseg_desc {
+  int32_t arch;          /* pclseg_arch */
+  int32_t height;        /* ZENITH_LEVEL  */
+  int32_t width;         /* AZIMUTH_LEVEL; must be divisible by 16 (four stride-2 stages) */
+  int32_t num_class;     /* NUM_CLASS */
+  int32_t none_index;    /* CLASSES.index("None"): prediction written where mask is false */
+  int32_t output_stride; /* Darknet OUTPUT_STRIDE (only 16 is used by the reference configs;
+                            8/16/32 accepted); ignored for SqueezeSegV2 */
+  int32_t device;        /* HIP device ordinal */
+  int32_t micro_batch;   /* scans swept through the network per kernel sequence; 0 = auto.
+                            Any n may be passed to forward; it is processed in chunks. */
+  uint32_t flags;
+  double mean[5];        /* INPUT_MEAN (x, y, z, intensity, depth) */
+  double std[5];         /* INPUT_STD */
+} pclseg_desc;
+
+/* CPU-only description of what a desc builds (no GPU needed). */
+typedef struct pclseg_plan_info {
+  int32_t num_ops;            /* kernel launches per micro-batch */
+  int32_t num_weights;        /* Keras tensors the model owns */
+  int32_t num_tensors;        /* activation tensors */
+  int32_t micro_batch;        /* resolved micro-batch */
+  int64_t num_params;         /* scalars in all Keras tensors */
+  int64_t alg_macs_per_scan;  /* multiply-accumulates of every Conv2D / Conv2DTranspose */
+  int64_t alg_bytes_per_scan; /* module-granular fp32 traffic, no weights */
+  int64_t workspace_bytes;    /* activation arena for one micro-batch */
+  int64_t packed_weight_bytes;
+} pclseg_plan_info;
+
+int pclseg_version(void);
+
+/* Last error text of `h` (or of the last failed handle-less call when h is NULL).
+ * Never returns NULL. */
+const char* pclseg_last_error(const pclseg_handle* h);
+
+/* Validate a desc and describe the graph it builds.  Runs without a GPU. */
+int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out);
+
+/* Build the model graph on desc->device: replaces constructing the Keras model
+ * (SqueezeSegV2(mc) nets/SqueezeSegV2.py:220-283; Darknet(mc) nets/Darknet.py:149-260).
+ * Fails with PCLSEG_ERR_HIP when no GPU is present: there is no CPU fallback. */
+int pclseg_create(const pclseg_desc* desc, pclseg_handle** out);
+int pclseg_destroy(pclseg_handle* h);
+
+/* Weight inventory, in layer-construction order, named by Keras attribute path
+ * ("fire2/squeeze/kernel", "enc3/residual_1/bn2/moving_variance", ...). */
+int pclseg_num_weights(const pclseg_handle* h);
+int pclseg_weight_info(const pclseg_handle* h, int index, char* name, size_t name_cap,
+                       int64_t shape[4], int* ndim);
+
+/* Bind one Keras tensor (host pointer, float32, Keras layout: conv (kh,kw,Cin,Cout),
+ * transposed conv (1,4,Cout,Cin), vectors (C,)).  Replaces load_model's variable restore
+ * (inference.py:39).  The data is copied. */
+int pclseg_set_weight(pclseg_handle* h, const char* keras_path, const float* data,
+                      const int64_t* shape, int ndim);
+
+/* Fold BatchNorm (eps = 1e-3, inference form) into the conv weights, repack for the MFMA
+ * kernels and upload.  Must be called once, after every tensor has been set. */
+int pclseg_finalize(pclseg_handle* h);
+
+/* Use `hip_stream` (a hipStream_t) for all subsequent work; NULL = the legacy default stream. */
+int pclseg_set_stream(pclseg_handle* h, void* hip_stream);
+int pclseg_sync(pclseg_handle* h);
+
+/* The reference-shaped call: model([lidar, mask]) -> (probabilities, predictions)
+ * (nets/SegmentationNetwork.py:55-69, nets/SqueezeSegV2.py:285-325, nets/Darknet.py:279-314).
+ *   lidar  float32 [n,H,W,6]  normalised, channel 5 = mask as 0/1
+ *   mask   uint8   [n,H,W]    0 = no point
+ *   preds  int32   [n,H,W]    out, required
+ *   probs  float32 [n,H,W,NC] out, optional (NULL: softmax is not materialised and the
+ *                             argmax is taken over the logits, which is the same argmax)
+ *   logits float32 [n,H,W,NC] out, optional */
+int pclseg_forward(pclseg_handle* h, const float* lidar, const uint8_t* mask, int n,
+                   int32_t* preds, float* probs, float* logits, int mem);
+
+/* Same, starting from raw scans: does the caller-side pre-processing of the reference on the
+ * device (inference.py:50-62; data_loader/data_loader.py:156-171): mask = depth > 0,
+ * (x - mean)/std in float64, invalid pixels zeroed, mask appended as 6th channel.
+ *   scans    float32 [n,H,W,5]  x, y, z, intensity, depth
+ *   mask_out uint8   [n,H,W]    out, optional */
+int pclseg_forward_raw(pclseg_handle* h, const float* scans, int n, int32_t* preds,
+                       float* probs, float* logits, uint8_t* mask_out, int mem);
+
+/* Debug: activation tensors of the LAST micro-batch (meaningful with
+ * PCLSEG_FLAG_KEEP_ACTIVATIONS).  shape = {micro-batch scans held, H, W, C}. */
+int pclseg_num_tensors(const pclseg_handle* h);
+int pclseg_tensor_info(const pclseg_handle* h, int index, char* name, size_t name_cap,
+                       int64_t shape[4]);
+int pclseg_read_tensor(pclseg_handle* h, int index, float* host_out, size_t capacity_floats);
+
+/* ---- single-operator entry points (device pointers, handle-less, default stream, synchronous).
+ * They run the same kernels the graph uses and exist for operator-level parity tests. */
+
+/* inference.py:50-62.  scans [n,H,W,5] -> lidar [n,H,W,6], mask [n,H,W]. */
+int pclseg_op_normalize(const float* scans, int n, int h, int w, const double mean[5],
+                        const double std[5], float* lidar6, uint8_t* mask);
+
+/* Conv2D SAME, strides (1, stride_w), kernel (kh,kw,Cin,Cout) host pointer, optional bias and
+ * BatchNorm (host pointers, NULL = absent), activation 0 none / 1 relu / 2 leaky(0.1) /
+ * 3 sigmoid, optional residual added after the activation.  x, residual, y: device, NHWC;
+ * Cin and Cout multiples of 4. */
+int pclseg_op_conv2d(const float* x, int n, int h, int w, int cin, const float* kernel, int kh,
+                     int kw, int cout, int stride_w, const float* bias, const float* bn_gamma,
+                     const float* bn_beta, const float* bn_mean, const float* bn_var, int act,
+                     const float* residual, float* y);
+
+/* Conv2DTranspose kernel (1,4), strides (1,2), SAME: kernel (1,4,Cout,Cin) host pointer.
+ * y [n,h,2w,Cout]. */
+int pclseg_op_conv2d_transpose(const float* x, int n, int h, int w, int cin, const float* kernel,
+                               int cout, const float* bias, const float* bn_gamma,
+                               const float* bn_beta, const float* bn_mean, const float* bn_var,
+                               int act, float* y);
+
+/* MaxPool k x k, strides (1, stride_w), SAME (padding never wins). C multiple of 4. */
+int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int stride_w, float* y);
+
+/* conv 3x3 Cin->NC + bias, then nets/SegmentationNetwork.py:58-69.  kernel/bias host pointers;
+ * preds required; probs/logits optional device pointers. */
+int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int cin,
+                   const float* kernel, const float* bias, int num_class, int none_index,
+                   int32_t* preds, float* probs, float* logits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCLSEG_H_ */

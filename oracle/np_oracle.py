@@ -275,8 +275,10 @@ def darknet_logits(weights, lidar, num_layers, output_stride=16, dtype=np.float6
   for i in range(5):                                                         # :293-302
     p = "enc%d" % (i + 1)
     y = leaky_relu(W.bn(W.conv(x, p + "/conv1", stride_w=enc_strides[i]), p + "/bn1"))
+    t[p + "/conv1"] = y
     for j in range(blocks[i]):
       y = basic_block(W, y, "%s/residual_%d" % (p, j))
+      t["%s/residual_%d/conv2" % (p, j)] = y
     x, os_ = enc_step(x, y, os_)
     t[p] = x
   for k in range(5):                                                         # :305-309
@@ -286,12 +288,14 @@ def darknet_logits(weights, lidar, num_layers, output_stride=16, dtype=np.float6
     else:
       y = W.conv(x, p + "/conv1")
     y = leaky_relu(W.bn(y, p + "/bn1"))
+    t[p + ("/upconv1" if dec_strides[k] == 2 else "/conv1")] = y
     y = basic_block(W, y, p + "/block")
     if y.shape[2] > x.shape[2]:
       os_ //= 2
       y = y + skips[os_]
     x = y
     t[p] = x
+    t[p + "/block/conv2"] = x
   logits = W.conv(x, "head")                                                 # :312
   t["logits"] = logits
   return logits

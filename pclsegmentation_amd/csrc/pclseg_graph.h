@@ -1,0 +1,479 @@
+// pclseg_graph.h — host-side graph description of the three networks (no HIP in here).
+//
+// Builds, from a pclseg_desc, the ordered operator list, the activation tensors with their
+// lifetimes, the Keras weight inventory and the workspace plan.  The same structure drives
+// pclseg_plan (CPU-only) and the device engine.
+//
+// reference graphs: nets/SqueezeSegV2.py:285-325 (CAM :66-70, FIRE :123-127, FIREUP :191-199),
+// nets/Darknet.py:279-314 (BasicBlock :54-66, EncoderLayer :96-103, DecoderLayer :130-138,
+// stride logic :158-181/:215-231, skip bookkeeping :263-277).
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pclseg.h"
+
+namespace pclseg {
+
+enum OpKind { OP_CONV = 0, OP_DECONV = 1, OP_POOL = 2, OP_HEAD = 3 };
+
+struct WeightInfo {
+  std::string name;
+  int ndim;
+  int64_t shape[4];
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+  }
+};
+
+struct TensorInfo {
+  std::string name;
+  int H, W, C;
+  int def_op = -1, last_op = -1;
+  int64_t offset = -1;  // floats, into the activation arena
+  int64_t scan_floats() const { return (int64_t)H * W * C; }
+};
+
+struct Op {
+  int kind = OP_CONV;
+  std::string name;    // Keras layer path, e.g. "fire2/expand3x3"
+  std::string bn;      // Keras BatchNormalization path, "" = none
+  bool has_bias = true;
+  int in = -1, out = -1, res1 = -1, res2 = -1;
+  bool res1_mul = false;
+  int cin_t = 0;       // channels of the input tensor (8 for the zero-padded network input)
+  int cin_k = 0;       // Cin of the Keras kernel (6 for the network input)
+  int cout = 0;
+  int kh = 1, kw = 1, sw = 1;
+  int act = 0;
+  int co_off = 0;
+  // packed parameters: float offsets into the device parameter blob
+  int64_t w_off = 0, b_off = 0;
+  int nc16 = 0, nctp = 0, nt = 0;
+};
+
+struct Graph {
+  pclseg_desc desc;
+  int micro_batch = 1;
+  std::vector<Op> ops;
+  std::vector<TensorInfo> tensors;
+  std::vector<WeightInfo> weights;
+  std::map<std::string, int> weight_index;
+  int t_input = -1;  // lidar8
+  int64_t arena_floats = 0;  // per micro-batch
+  int64_t alg_macs = 0, alg_bytes = 0, num_params = 0, packed_floats = 0;
+  std::string error;
+};
+
+inline void same_pad(int size, int k, int s, int* out, int* before) {
+  *out = (size + s - 1) / s;
+  int total = std::max((*out - 1) * s + k - size, 0);
+  *before = total / 2;
+}
+
+inline int choose_nt(int nct) {
+  if (nct % 4 == 0) return 4;
+  if (nct % 3 == 0) return 3;
+  if (nct % 2 == 0) return 2;
+  if (nct == 1) return 1;
+  return 4;
+}
+
+class GraphBuilder {
+ public:
+  explicit GraphBuilder(Graph* g) : g_(g) {}
+
+  int tensor(const std::string& name, int H, int W, int C) {
+    TensorInfo t;
+    t.name = name;
+    t.H = H;
+    t.W = W;
+    t.C = C;
+    g_->tensors.push_back(t);
+    return (int)g_->tensors.size() - 1;
+  }
+
+  void add_weight(const std::string& name, std::vector<int64_t> shape) {
+    WeightInfo w;
+    w.name = name;
+    w.ndim = (int)shape.size();
+    for (int i = 0; i < 4; ++i) w.shape[i] = i < w.ndim ? shape[i] : 1;
+    g_->weight_index[name] = (int)g_->weights.size();
+    g_->num_params += w.numel();
+    g_->weights.push_back(w);
+  }
+  void add_bn(const std::string& p, int c) {
+    add_weight(p + "/gamma", {c});
+    add_weight(p + "/beta", {c});
+    add_weight(p + "/moving_mean", {c});
+    add_weight(p + "/moving_variance", {c});
+  }
+
+  void touch(int t, int op) {
+    if (t < 0) return;
+    TensorInfo& ti = g_->tensors[t];
+    if (ti.def_op < 0) ti.def_op = op;
+    ti.last_op = std::max(ti.last_op, op);
+  }
+
+  // Conv2D SAME (+bias) (+BN) (+act), optional residuals, optional channel-slice output.
+  // `out` < 0 creates the output tensor; returns the output tensor id.
+  int conv(const std::string& name, int in, int kh, int kw, int cout, int sw, bool bias,
+           const std::string& bn, int act, int out = -1, int co_off = 0, int res1 = -1,
+           bool res1_mul = false, int res2 = -1, int cin_k = -1) {
+    const TensorInfo ti = g_->tensors[in];
+    Op op;
+    op.kind = OP_CONV;
+    op.name = name;
+    op.bn = bn;
+    op.has_bias = bias;
+    op.in = in;
+    op.cin_t = ti.C;
+    op.cin_k = cin_k < 0 ? ti.C : cin_k;
+    op.cout = cout;
+    op.kh = kh;
+    op.kw = kw;
+    op.sw = sw;
+    op.act = act;
+    op.co_off = co_off;
+    op.res1 = res1;
+    op.res1_mul = res1_mul;
+    op.res2 = res2;
+    int wo, pl;
+    same_pad(ti.W, kw, sw, &wo, &pl);
+    if (out < 0) out = tensor(name, ti.H, wo, cout);
+    op.out = out;
+    // weights are declared once per Keras layer (a transposed conv is two ops)
+    add_weight(name + "/kernel", {kh, kw, op.cin_k, cout});
+    if (bias) add_weight(name + "/bias", {cout});
+    if (!bn.empty()) add_bn(bn, cout);
+    g_->alg_macs += (int64_t)ti.H * wo * kh * kw * op.cin_k * cout;
+    push(op);
+    return out;
+  }
+
+  // Conv2DTranspose (1,4)/(1,2) SAME (+bias) (+BN) (+act): two parity ops.
+  int deconv(const std::string& name, int in, int cout, const std::string& bn, int act) {
+    const TensorInfo ti = g_->tensors[in];
+    int out = tensor(name, ti.H, ti.W * 2, cout);
+    add_weight(name + "/kernel", {1, 4, cout, ti.C});
+    add_weight(name + "/bias", {cout});
+    if (!bn.empty()) add_bn(bn, cout);
+    g_->alg_macs += (int64_t)ti.H * ti.W * 4 * ti.C * cout;
+    for (int parity = 0; parity < 2; ++parity) {
+      Op op;
+      op.kind = OP_DECONV;
+      op.name = name;
+      op.bn = bn;
+      op.has_bias = true;
+      op.in = in;
+      op.out = out;
+      op.cin_t = op.cin_k = ti.C;
+      op.cout = cout;
+      op.kh = 1;
+      op.kw = 2;
+      op.sw = parity;  // parity stored in sw for OP_DECONV
+      op.act = act;
+      push(op);
+    }
+    return out;
+  }
+
+  int pool(const std::string& name, int in, int k, int sw) {
+    const TensorInfo ti = g_->tensors[in];
+    int wo, pl;
+    same_pad(ti.W, k, sw, &wo, &pl);
+    Op op;
+    op.kind = OP_POOL;
+    op.name = name;
+    op.in = in;
+    op.kh = op.kw = k;
+    op.sw = sw;
+    op.cin_t = op.cin_k = op.cout = ti.C;
+    op.out = tensor(name, ti.H, wo, ti.C);
+    push(op);
+    return op.out;
+  }
+
+  void head(const std::string& name, int in, int num_class) {
+    const TensorInfo ti = g_->tensors[in];
+    Op op;
+    op.kind = OP_HEAD;
+    op.name = name;
+    op.in = in;
+    op.cin_t = op.cin_k = ti.C;
+    op.cout = num_class;
+    op.kh = op.kw = 3;
+    op.sw = 1;
+    op.has_bias = true;
+    add_weight(name + "/kernel", {3, 3, ti.C, num_class});
+    add_weight(name + "/bias", {num_class});
+    g_->alg_macs += (int64_t)ti.H * ti.W * 9 * ti.C * num_class;
+    push(op);
+  }
+
+  // module-granular traffic accounting: floats read / written per scan
+  void module_bytes(int64_t read_floats, int64_t write_floats, int64_t extra_bytes = 0) {
+    g_->alg_bytes += 4 * (read_floats + write_floats) + extra_bytes;
+  }
+  int64_t fl(int t, int c_override = -1) const {
+    const TensorInfo& ti = g_->tensors[t];
+    return (int64_t)ti.H * ti.W * (c_override < 0 ? ti.C : c_override);
+  }
+
+ private:
+  void push(const Op& op) {
+    int idx = (int)g_->ops.size();
+    g_->ops.push_back(op);
+    touch(op.in, idx);
+    touch(op.out, idx);
+    touch(op.res1, idx);
+    touch(op.res2, idx);
+  }
+  Graph* g_;
+};
+
+// ---- SqueezeSegV2 (reference: nets/SqueezeSegV2.py:285-325)
+inline void build_squeezesegv2(Graph* g) {
+  GraphBuilder b(g);
+  const int H = g->desc.height, W = g->desc.width, NC = g->desc.num_class;
+  const int x_in = b.tensor("input", H, W, 8);
+  g->t_input = x_in;
+
+  auto cam = [&](const std::string& p, int x) {
+    const int C = g->tensors[x].C;
+    const int pooled = b.pool(p + "/pool", x, 7, 1);
+    const int sq = b.conv(p + "/squeeze", pooled, 1, 1, C / 16, 1, true, p + "/squeeze_bn", 1);
+    // excitation -> BN -> sigmoid, gate multiplies the un-pooled input (:69-70)
+    const int out = b.tensor(p, g->tensors[x].H, g->tensors[x].W, C);
+    b.conv(p + "/excitation", sq, 1, 1, C, 1, true, p + "/excitation_bn", 3, out, 0, x, true);
+    b.module_bytes(b.fl(x), b.fl(out));
+    return out;
+  };
+  auto fire = [&](const std::string& p, int x, int sq_c, int e1, int e3, bool up, int skip) {
+    int s = b.conv(p + "/squeeze", x, 1, 1, sq_c, 1, true, p + "/squeeze_bn", 1);
+    if (up) s = b.deconv(p + "/upconv", s, sq_c, "", 1);  // ReLU, no BN (:194)
+    const int out = b.tensor(p, g->tensors[s].H, g->tensors[s].W, e1 + e3);
+    b.conv(p + "/expand1x1", s, 1, 1, e1, 1, true, p + "/expand1x1_bn", 1, out, 0, skip);
+    b.conv(p + "/expand3x3", s, 3, 3, e3, 1, true, p + "/expand3x3_bn", 1, out, e1, skip);
+    b.module_bytes(b.fl(x) + (skip >= 0 ? b.fl(skip) : 0), b.fl(out));
+    return out;
+  };
+  auto pool = [&](const std::string& p, int x) {
+    const int out = b.pool(p, x, 3, 2);
+    b.module_bytes(b.fl(x), b.fl(out));
+    return out;
+  };
+
+  int x = b.conv("conv1", x_in, 3, 3, 64, 2, true, "bn1", 1, -1, 0, -1, false, -1, 6);  // :289
+  b.module_bytes(b.fl(x_in, 6), b.fl(x));
+  const int cam1 = cam("cam1", x);                                                          // :291
+  const int skip = b.conv("conv1_skip", x_in, 1, 1, 64, 1, true, "bn1_skip", 0, -1, 0, -1, false,
+                          -1, 6);                                                           // :293
+  b.module_bytes(b.fl(x_in, 6), b.fl(skip));
+  x = pool("pool1", cam1);                                                                  // :295
+  x = fire("fire2", x, 16, 64, 64, false, -1);
+  x = cam("cam2", x);
+  x = fire("fire3", x, 16, 64, 64, false, -1);
+  const int cam3 = cam("cam3", x);                                                          // :299
+  x = pool("pool3", cam3);                                                                  // :301
+  x = fire("fire4", x, 32, 128, 128, false, -1);
+  const int fire5 = fire("fire5", x, 32, 128, 128, false, -1);                              // :303
+  x = pool("pool5", fire5);                                                                 // :305
+  x = fire("fire6", x, 48, 192, 192, false, -1);
+  x = fire("fire7", x, 48, 192, 192, false, -1);
+  x = fire("fire8", x, 64, 256, 256, false, -1);
+  x = fire("fire9", x, 64, 256, 256, false, -1);                                            // :309
+  x = fire("fire10", x, 64, 128, 128, true, fire5);                                         // :312-313
+  x = fire("fire11", x, 32, 64, 64, true, cam3);                                            // :314-315
+  x = fire("fire12", x, 16, 32, 32, true, cam1);                                            // :316-317
+  x = fire("fire13", x, 16, 32, 32, true, skip);                                            // :318-319
+  b.head("conv14", x, NC);                                                                  // :323-325
+  b.module_bytes(b.fl(x), (int64_t)H * W, (int64_t)H * W);  // + mask 1 B/px, int32 preds out
+}
+
+// ---- Darknet-21/53 (reference: nets/Darknet.py:279-314)
+inline void darknet_strides(int output_stride, int enc[5], int dec[5]) {
+  for (int i = 0; i < 5; ++i) enc[i] = dec[i] = 2;
+  int cur = 32;
+  if (output_stride <= cur) {
+    for (int i = 0; i < 5; ++i) {  // reversed(encoder_strides)
+      if (cur != output_stride) {
+        if (enc[4 - i] == 2) { cur /= 2; enc[4 - i] = 1; }
+        if (cur == output_stride) break;
+      }
+    }
+  }
+  cur = 32;
+  for (int i = 0; i < 5; ++i) {
+    if (cur != output_stride) {
+      if (dec[i] == 2) { cur /= 2; dec[i] = 1; }
+      if (cur == output_stride) break;
+    }
+  }
+}
+
+inline void build_darknet(Graph* g, int num_layers) {
+  GraphBuilder b(g);
+  const int H = g->desc.height, W = g->desc.width, NC = g->desc.num_class;
+  static const int blocks21[5] = {1, 1, 2, 2, 1}, blocks53[5] = {1, 2, 8, 8, 4};
+  const int* nb = num_layers == 21 ? blocks21 : blocks53;
+  int enc_s[5], dec_s[5];
+  darknet_strides(g->desc.output_stride, enc_s, dec_s);
+  const int x_in = b.tensor("input", H, W, 8);
+  g->t_input = x_in;
+  const int LR = 2;  // LeakyReLU(0.1)
+
+  // BasicBlock: x + lrelu(bn2(conv3x3(lrelu(bn1(conv1x1(x)))))) (+ decoder skip)
+  auto block = [&](const std::string& p, int x, int mid, int c, int skip) {
+    const int m = b.conv(p + "/conv1", x, 1, 1, mid, 1, false, p + "/bn1", LR);
+    const int y = b.conv(p + "/conv2", m, 3, 3, c, 1, false, p + "/bn2", LR, -1, 0, x, false, skip);
+    b.module_bytes(b.fl(x) + (skip >= 0 ? b.fl(skip) : 0), b.fl(y));
+    return y;
+  };
+
+  int x = b.conv("conv1", x_in, 3, 3, 32, 1, false, "bn1", LR, -1, 0, -1, false, -1, 6);  // :288-290
+  b.module_bytes(b.fl(x_in, 6), b.fl(x));
+  static const int enc_planes[5][2] = {{32, 64}, {64, 128}, {128, 256}, {256, 512}, {512, 1024}};
+  std::vector<int> skips;  // inputs of the W-shrinking encoder layers (:263-269)
+  for (int i = 0; i < 5; ++i) {
+    const std::string p = "enc" + std::to_string(i + 1);
+    if (enc_s[i] == 2) skips.push_back(x);
+    int y = b.conv(p + "/conv1", x, 3, 3, enc_planes[i][1], enc_s[i], false, p + "/bn1", LR);
+    b.module_bytes(b.fl(x), b.fl(y));
+    for (int j = 0; j < nb[i]; ++j)
+      y = block(p + "/residual_" + std::to_string(j), y, enc_planes[i][0], enc_planes[i][1], -1);
+    x = y;
+  }
+  static const int dec_planes[5][2] = {{1024, 512}, {512, 256}, {256, 128}, {128, 64}, {64, 32}};
+  for (int k = 0; k < 5; ++k) {
+    const std::string p = "dec" + std::to_string(5 - k);
+    int y;
+    int skip = -1;
+    if (dec_s[k] == 2) {
+      y = b.deconv(p + "/upconv1", x, dec_planes[k][1], p + "/bn1", LR);
+      skip = skips.back();  // matching encoder input (:271-277)
+      skips.pop_back();
+    } else {
+      y = b.conv(p + "/conv1", x, 3, 3, dec_planes[k][1], 1, true, p + "/bn1", LR);
+    }
+    b.module_bytes(b.fl(x), b.fl(y));
+    x = block(p + "/block", y, dec_planes[k][0], dec_planes[k][1], skip);
+  }
+  b.head("head", x, NC);                                                                    // :312-314
+  b.module_bytes(b.fl(x), (int64_t)H * W, (int64_t)H * W);
+}
+
+// ---- liveness-based first-fit placement of activation tensors in one arena
+inline void plan_workspace(Graph* g) {
+  struct Live { int64_t off, size; int last; };
+  std::vector<Live> live;
+  const bool keep = (g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS) != 0;
+  std::vector<int> order(g->tensors.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b2) {
+    return g->tensors[a].def_op < g->tensors[b2].def_op;
+  });
+  int64_t top = 0;
+  for (int ti : order) {
+    TensorInfo& t = g->tensors[ti];
+    const int64_t size = ((t.scan_floats() * g->micro_batch + 63) / 64) * 64;  // 256-B granules
+    if (keep) {
+      t.offset = top;
+      top += size;
+      continue;
+    }
+    // the network input is written before op 0 (def_op == 0 as a reader): treat def as -1
+    const int def = (ti == g->t_input) ? -1 : t.def_op;
+    std::vector<Live> still;
+    for (const Live& l : live)
+      if (l.last >= def) still.push_back(l);
+    live.swap(still);
+    std::sort(live.begin(), live.end(), [](const Live& a, const Live& b2) { return a.off < b2.off; });
+    int64_t off = 0;
+    for (const Live& l : live) {
+      if (off + size <= l.off) break;
+      off = std::max(off, l.off + l.size);
+    }
+    t.offset = off;
+    live.push_back({off, size, t.last_op});
+    top = std::max(top, off + size);
+  }
+  g->arena_floats = top;
+}
+
+inline int resolve_micro_batch(const pclseg_desc& d) {
+  if (d.micro_batch > 0) return d.micro_batch;
+  const int64_t px = (int64_t)d.height * d.width;
+  int64_t mb = (int64_t)(1 << 19) / std::max<int64_t>(px, 1);
+  return (int)std::min<int64_t>(std::max<int64_t>(mb, 1), 16);
+}
+
+// Validate desc and build the graph.  Returns a pclseg_status.
+inline int build_graph(const pclseg_desc* d, Graph* g) {
+  if (!d) { g->error = "desc is NULL"; return PCLSEG_ERR_BAD_ARG; }
+  g->desc = *d;
+  if (d->arch < 0 || d->arch > PCLSEG_ARCH_DARKNET53) {
+    g->error = "unknown arch " + std::to_string(d->arch);
+    return PCLSEG_ERR_BAD_ARG;
+  }
+  if (d->height <= 0 || d->width <= 0) {
+    g->error = "height and width must be positive";
+    return PCLSEG_ERR_BAD_SHAPE;
+  }
+  if (d->num_class < 2 || d->num_class > 64) {
+    g->error = "num_class must be in [2, 64]";
+    return PCLSEG_ERR_BAD_ARG;
+  }
+  if (d->none_index < 0 || d->none_index >= d->num_class) {
+    g->error = "none_index out of range";
+    return PCLSEG_ERR_BAD_ARG;
+  }
+  for (int i = 0; i < 5; ++i)
+    if (!(d->std[i] > 0.0) || !std::isfinite(d->mean[i])) {
+      g->error = "std must be positive and mean finite";
+      return PCLSEG_ERR_BAD_ARG;
+    }
+  int down = 16;  // four stride-2 stages along W, undone by four x2 transposed convs + skips
+  if (d->arch != PCLSEG_ARCH_SQUEEZESEGV2) {
+    if (d->output_stride != 8 && d->output_stride != 16 && d->output_stride != 32) {
+      g->error = "output_stride must be 8, 16 or 32";
+      return PCLSEG_ERR_BAD_ARG;
+    }
+    down = d->output_stride;
+  }
+  if (d->width % down != 0) {
+    g->error = "width " + std::to_string(d->width) + " is not divisible by " + std::to_string(down) +
+               " (encoder/decoder skip shapes would not match)";
+    return PCLSEG_ERR_BAD_SHAPE;
+  }
+  g->micro_batch = resolve_micro_batch(*d);
+  if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) build_squeezesegv2(g);
+  else build_darknet(g, d->arch == PCLSEG_ARCH_DARKNET21 ? 21 : 53);
+  // packed-parameter geometry
+  int64_t pf = 0;
+  for (Op& op : g->ops) {
+    if (op.kind == OP_POOL) continue;
+    op.nc16 = (op.cin_t + 15) / 16;
+    const int nct = (op.cout + 15) / 16;
+    op.nt = (op.kind == OP_HEAD) ? nct : choose_nt(nct);
+    op.nctp = ((nct + op.nt - 1) / op.nt) * op.nt;
+    const int taps = op.kh * op.kw;
+    op.w_off = pf;
+    pf += (int64_t)taps * op.nc16 * op.nctp * 256;
+    op.b_off = pf;
+    pf += (int64_t)op.nctp * 16;
+  }
+  g->packed_floats = pf;
+  plan_workspace(g);
+  return PCLSEG_OK;
+}
+
+}  // namespace pclseg

@@ -1,0 +1,92 @@
+"""Multi-GPU sharding: one process per GPU, scans split by contiguous ranges, weights
+broadcast once over RCCL/xGMI.  The reference has no distributed code at all
+(it only sets memory growth on physical_devices[0], inference.py:116-118),
+so this is a new capability built for the path's natural parallelism: every scan is an
+independent forward pass (BatchNorm in inference mode has no cross-sample statistics),
+hence NO collective in steady state — only the start-up weight broadcast and, optionally,
+a gather of int32 predictions.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+  """(rank, local_rank, world_size) from the torchrun environment (1 process if unset)."""
+  return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+          int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None):
+  """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE.
+  backend defaults to nccl (= RCCL on ROCm) when a GPU is visible, else gloo."""
+  rank, local_rank, world = env_world()
+  if world > 1 and not dist.is_initialized():
+    if backend is None:
+      backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+      torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+  return rank, local_rank, world
+
+
+def shard_range(n, rank, world):
+  """Contiguous split of n scans: rank r owns [lo, hi); sizes differ by at most one."""
+  base, rem = divmod(n, world)
+  lo = rank * base + min(rank, rem)
+  return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_weights(spec, weights):
+  """Flatten a weight set into one float32 vector in spec order."""
+  return np.concatenate([np.asarray(weights[w.path], np.float32).ravel() for w in spec])
+
+
+def unpack_weights(spec, flat):
+  out, off = {}, 0
+  for w in spec:
+    k = int(np.prod(w.shape))
+    out[w.path] = np.asarray(flat[off:off + k], np.float32).reshape(w.shape)
+    off += k
+  if off != len(flat):
+    raise ValueError("weight blob has %d scalars, spec needs %d" % (len(flat), off))
+  return out
+
+
+def broadcast_weights(spec, weights, src=0, device=None):
+  """One broadcast of the packed weight blob (3.75 MB SqueezeSegV2 ... 212 MB Darknet-53).
+  ``weights`` is only read on rank ``src``; every rank returns the full dict."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return weights
+  n = sum(int(np.prod(w.shape)) for w in spec)
+  if device is None:
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" \
+      else torch.device("cpu")
+  if dist.get_rank() == src:
+    blob = torch.from_numpy(pack_weights(spec, weights)).to(device)
+  else:
+    blob = torch.empty(n, dtype=torch.float32, device=device)
+  dist.broadcast(blob, src=src)
+  return unpack_weights(spec, blob.cpu().numpy())
+
+
+def gather_predictions(local_preds, n_total, dst=0):
+  """Optional: collect every rank's int32 predictions [n_local,H,W] on rank ``dst`` in scan
+  order (ranks may hold different counts)."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return local_preds
+  world, rank = dist.get_world_size(), dist.get_rank()
+  counts = [shard_range(n_total, r, world) for r in range(world)]
+  max_n = max(hi - lo for lo, hi in counts)
+  pad = torch.zeros((max_n,) + tuple(local_preds.shape[1:]), dtype=local_preds.dtype,
+                    device=local_preds.device)
+  pad[:local_preds.shape[0]] = local_preds
+  bufs = [torch.empty_like(pad) for _ in range(world)]
+  dist.all_gather(bufs, pad)
+  if rank != dst:
+    return None
+  return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, counts)], dim=0)

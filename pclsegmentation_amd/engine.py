@@ -1,0 +1,287 @@
+"""ctypes binding of libpclseg.so (C ABI declared in include/pclseg.h).
+
+The library is the product: there is no Python/NumPy/PyTorch implementation of any
+network operation in this package, and no CPU fallback.  If the shared library is
+missing or no MI355X is visible, construction fails with a RuntimeError.
+
+PyTorch is used by callers only as a device-memory container: tensors are handed over as
+raw ``data_ptr()`` device pointers together with the current HIP stream.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpclseg.so")
+
+OK = 0
+ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5, -6
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_KEEP_ACTIVATIONS = 1
+
+ARCH_IDS = {"squeezesegv2": 0, "darknet21": 1, "darknet53": 2}
+ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
+
+# every symbol include/pclseg.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+  "pclseg_version", "pclseg_last_error", "pclseg_plan", "pclseg_create", "pclseg_destroy",
+  "pclseg_num_weights", "pclseg_weight_info", "pclseg_set_weight", "pclseg_finalize",
+  "pclseg_set_stream", "pclseg_sync", "pclseg_forward", "pclseg_forward_raw",
+  "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
+  "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
+]
+
+
+class Desc(ctypes.Structure):
+  _fields_ = [("arch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+              ("num_class", ctypes.c_int32), ("none_index", ctypes.c_int32),
+              ("output_stride", ctypes.c_int32), ("device", ctypes.c_int32),
+              ("micro_batch", ctypes.c_int32), ("flags", ctypes.c_uint32),
+              ("mean", ctypes.c_double * 5), ("std", ctypes.c_double * 5)]
+
+
+class PlanInfo(ctypes.Structure):
+  _fields_ = [("num_ops", ctypes.c_int32), ("num_weights", ctypes.c_int32),
+              ("num_tensors", ctypes.c_int32), ("micro_batch", ctypes.c_int32),
+              ("num_params", ctypes.c_int64), ("alg_macs_per_scan", ctypes.c_int64),
+              ("alg_bytes_per_scan", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64),
+              ("packed_weight_bytes", ctypes.c_int64)]
+
+
+_lib = None
+
+
+def load_library():
+  """dlopen libpclseg.so and declare signatures.  Raises RuntimeError if it is not built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+      "libpclseg.so not found at %s — build it with `make` (or __graft_entry__.build()); "
+      "this engine has no CPU fallback" % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  vp, i32, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+  lib.pclseg_version.restype = ctypes.c_int
+  lib.pclseg_last_error.restype = ctypes.c_char_p
+  lib.pclseg_last_error.argtypes = [vp]
+  lib.pclseg_plan.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(PlanInfo)]
+  lib.pclseg_create.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(vp)]
+  lib.pclseg_destroy.argtypes = [vp]
+  lib.pclseg_num_weights.argtypes = [vp]
+  lib.pclseg_weight_info.argtypes = [vp, i32, ctypes.c_char_p, ctypes.c_size_t,
+                                     ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+  lib.pclseg_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), i32]
+  lib.pclseg_finalize.argtypes = [vp]
+  lib.pclseg_set_stream.argtypes = [vp, vp]
+  lib.pclseg_sync.argtypes = [vp]
+  lib.pclseg_forward.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32]
+  lib.pclseg_forward_raw.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32]
+  lib.pclseg_num_tensors.argtypes = [vp]
+  lib.pclseg_tensor_info.argtypes = [vp, i32, ctypes.c_char_p, ctypes.c_size_t,
+                                     ctypes.POINTER(ctypes.c_int64)]
+  lib.pclseg_read_tensor.argtypes = [vp, i32, vp, ctypes.c_size_t]
+  d5 = ctypes.POINTER(ctypes.c_double)
+  lib.pclseg_op_normalize.argtypes = [vp, i32, i32, i32, d5, d5, vp, vp]
+  lib.pclseg_op_conv2d.argtypes = [vp, i32, i32, i32, i32, f32p, i32, i32, i32, i32, f32p, f32p,
+                                   f32p, f32p, f32p, i32, vp, vp]
+  lib.pclseg_op_conv2d_transpose.argtypes = [vp, i32, i32, i32, i32, f32p, i32, f32p, f32p, f32p,
+                                             f32p, f32p, i32, vp]
+  lib.pclseg_op_max_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp]
+  lib.pclseg_op_head.argtypes = [vp, vp, i32, i32, i32, i32, f32p, f32p, i32, i32, vp, vp, vp]
+  for name in EXPORTS:
+    fn = getattr(lib, name)
+    if name not in ("pclseg_last_error",):
+      fn.restype = ctypes.c_int
+  _lib = lib
+  return lib
+
+
+def _raise(rc, handle=None):
+  """Map a negative status to the exception the reference's Keras path would raise:
+  shape problems -> ValueError, everything else -> RuntimeError."""
+  lib = load_library()
+  msg = lib.pclseg_last_error(handle).decode("utf-8", "replace")
+  if rc in (ERR_BAD_SHAPE, ERR_BAD_ARG):
+    raise ValueError("pclseg: %s" % msg)
+  if rc == ERR_MISSING_WEIGHT:
+    raise KeyError("pclseg: %s" % msg)
+  if rc == ERR_OOM:
+    raise MemoryError("pclseg: %s" % msg)
+  raise RuntimeError("pclseg (status %d): %s" % (rc, msg))
+
+
+def check(rc, handle=None):
+  if rc != OK:
+    _raise(rc, handle)
+  return rc
+
+
+def make_desc(arch, height, width, num_class, none_index, mean, std, output_stride=16, device=0,
+              micro_batch=0, flags=0):
+  d = Desc()
+  d.arch = ARCH_IDS[arch] if isinstance(arch, str) else int(arch)
+  d.height, d.width = int(height), int(width)
+  d.num_class, d.none_index = int(num_class), int(none_index)
+  d.output_stride, d.device = int(output_stride), int(device)
+  d.micro_batch, d.flags = int(micro_batch), int(flags)
+  mean = np.asarray(mean, np.float64).reshape(5)
+  std = np.asarray(std, np.float64).reshape(5)
+  for i in range(5):
+    d.mean[i] = float(mean[i])
+    d.std[i] = float(std[i])
+  return d
+
+
+def plan(desc):
+  """CPU-only graph description (ops, params, algorithmic MACs/bytes, workspace)."""
+  lib = load_library()
+  info = PlanInfo()
+  check(lib.pclseg_plan(ctypes.byref(desc), ctypes.byref(info)))
+  return {k: getattr(info, k) for k, _ in PlanInfo._fields_}
+
+
+def _host_f32(a):
+  return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _ptr(x):
+  """Raw address of a NumPy array, a torch tensor, an int, or None."""
+  if x is None:
+    return None
+  if isinstance(x, int):
+    return ctypes.c_void_p(x)
+  if isinstance(x, np.ndarray):
+    return ctypes.c_void_p(x.ctypes.data)
+  return ctypes.c_void_p(x.data_ptr())  # torch.Tensor
+
+
+class Engine:
+  """One model graph on one device (wraps a pclseg_handle)."""
+
+  def __init__(self, desc):
+    self.lib = load_library()
+    self.desc = desc
+    self._h = ctypes.c_void_p()
+    check(self.lib.pclseg_create(ctypes.byref(desc), ctypes.byref(self._h)))
+    self.finalized = False
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self.lib.pclseg_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # -- weights
+  def weight_inventory(self):
+    out = []
+    n = self.lib.pclseg_num_weights(self._h)
+    name = ctypes.create_string_buffer(256)
+    shape = (ctypes.c_int64 * 4)()
+    ndim = ctypes.c_int()
+    for i in range(n):
+      check(self.lib.pclseg_weight_info(self._h, i, name, 256, shape, ctypes.byref(ndim)), self._h)
+      out.append((name.value.decode(), tuple(int(shape[j]) for j in range(ndim.value))))
+    return out
+
+  def set_weight(self, path, array):
+    a = _host_f32(array)
+    shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+    check(self.lib.pclseg_set_weight(self._h, path.encode(), _ptr(a), shape, a.ndim), self._h)
+
+  def set_weights(self, weights):
+    for path, _ in self.weight_inventory():
+      if path not in weights:
+        raise KeyError("pclseg: weight set has no tensor '%s'" % path)
+      self.set_weight(path, weights[path])
+
+  def finalize(self):
+    check(self.lib.pclseg_finalize(self._h), self._h)
+    self.finalized = True
+
+  # -- execution
+  def set_stream(self, stream_handle):
+    check(self.lib.pclseg_set_stream(self._h, ctypes.c_void_p(stream_handle or 0)), self._h)
+
+  def sync(self):
+    check(self.lib.pclseg_sync(self._h), self._h)
+
+  def forward(self, lidar, mask, n, preds, probs=None, logits=None, mem=MEM_DEVICE):
+    check(self.lib.pclseg_forward(self._h, _ptr(lidar), _ptr(mask), int(n), _ptr(preds),
+                                  _ptr(probs), _ptr(logits), mem), self._h)
+
+  def forward_raw(self, scans, n, preds, probs=None, logits=None, mask_out=None, mem=MEM_DEVICE):
+    check(self.lib.pclseg_forward_raw(self._h, _ptr(scans), int(n), _ptr(preds), _ptr(probs),
+                                      _ptr(logits), _ptr(mask_out), mem), self._h)
+
+  # -- debug
+  def tensors(self):
+    out = []
+    n = self.lib.pclseg_num_tensors(self._h)
+    name = ctypes.create_string_buffer(256)
+    shape = (ctypes.c_int64 * 4)()
+    for i in range(n):
+      check(self.lib.pclseg_tensor_info(self._h, i, name, 256, shape), self._h)
+      out.append((name.value.decode(), tuple(int(s) for s in shape)))
+    return out
+
+  def read_tensor(self, index):
+    name, shape = self.tensors()[index]
+    buf = np.empty(shape, np.float32)
+    check(self.lib.pclseg_read_tensor(self._h, index, _ptr(buf), buf.size), self._h)
+    return buf
+
+
+# ---- single-operator wrappers (device tensors in/out; used by the operator parity tests)
+def op_normalize(scans_dev, n, h, w, mean, std, lidar6_dev, mask_dev):
+  lib = load_library()
+  m = (ctypes.c_double * 5)(*np.asarray(mean, np.float64).reshape(5))
+  s = (ctypes.c_double * 5)(*np.asarray(std, np.float64).reshape(5))
+  check(lib.pclseg_op_normalize(_ptr(scans_dev), n, h, w, m, s, _ptr(lidar6_dev), _ptr(mask_dev)))
+
+
+def _opt(a):
+  return None if a is None else _host_f32(a)
+
+
+def op_conv2d(x_dev, n, h, w, cin, kernel, stride_w, bias, bn, act, residual_dev, y_dev):
+  lib = load_library()
+  k = _host_f32(kernel)
+  kh, kw, kcin, cout = k.shape
+  assert kcin == cin
+  b = _opt(bias)
+  g, be, mu, var = [_opt(v) for v in (bn if bn is not None else (None,) * 4)]
+  check(lib.pclseg_op_conv2d(_ptr(x_dev), n, h, w, cin, _ptr(k), kh, kw, cout, stride_w, _ptr(b),
+                             _ptr(g), _ptr(be), _ptr(mu), _ptr(var), ACT[act], _ptr(residual_dev),
+                             _ptr(y_dev)))
+
+
+def op_conv2d_transpose(x_dev, n, h, w, cin, kernel, bias, bn, act, y_dev):
+  lib = load_library()
+  k = _host_f32(kernel)
+  assert k.shape[:2] == (1, 4) and k.shape[3] == cin
+  cout = k.shape[2]
+  b = _opt(bias)
+  g, be, mu, var = [_opt(v) for v in (bn if bn is not None else (None,) * 4)]
+  check(lib.pclseg_op_conv2d_transpose(_ptr(x_dev), n, h, w, cin, _ptr(k), cout, _ptr(b), _ptr(g),
+                                       _ptr(be), _ptr(mu), _ptr(var), ACT[act], _ptr(y_dev)))
+
+
+def op_max_pool(x_dev, n, h, w, c, k, stride_w, y_dev):
+  check(load_library().pclseg_op_max_pool(_ptr(x_dev), n, h, w, c, k, stride_w, _ptr(y_dev)))
+
+
+def op_head(x_dev, mask_dev, n, h, w, cin, kernel, bias, none_index, preds_dev, probs_dev=None,
+            logits_dev=None):
+  k = _host_f32(kernel)
+  b = _host_f32(bias)
+  nc = k.shape[3]
+  check(load_library().pclseg_op_head(_ptr(x_dev), _ptr(mask_dev), n, h, w, cin, _ptr(k), _ptr(b),
+                                      nc, none_index, _ptr(preds_dev), _ptr(probs_dev),
+                                      _ptr(logits_dev)))

@@ -1,0 +1,3 @@
+from .SqueezeSegV2 import SqueezeSegV2
+from .Darknet import Darknet
+from .SegmentationNetwork import PCLSegmentationNetwork

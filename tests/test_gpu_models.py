@@ -1,0 +1,133 @@
+"""Whole-network parity on the MI355X against the committed golden vectors
+(tests/golden/model_*.npz, made by tests/golden/make_model_golden.py from the float64
+oracle) and, live, against the oracle including every intermediate activation.
+
+Acceptance (BASELINE.json north_star / SURVEY.md §8(c)): max |logit - oracle| <= 1e-3 and
+identical class IDs wherever the oracle's top-1/top-2 logit margin exceeds 2e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import pclsegmentation_amd as P
+from oracle import np_oracle as O
+from pclsegmentation_amd import engine as E
+from pclsegmentation_amd.utils.synthetic import synthetic_scans
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOGIT_TOL = 1e-3
+MARGIN = 2e-3
+
+CASES = [
+  ("ssv2_32x240", "squeezesegv2", "squeezesegv2"),
+  ("ssv2kitti_64x256", "squeezesegv2", "squeezesegv2kitti"),
+  ("ssv2_real_32x240", "squeezesegv2", "squeezesegv2"),
+  ("darknet21_32x240", "darknet21", "darknet21"),
+  ("darknet53_32x240", "darknet53", "darknet53"),
+  ("darknet53kitti_16x64", "darknet53", "darknet53kitti"),
+]
+
+
+def run_engine(model, raw, micro_batch=0, flags=0):
+  """raw host scans -> (preds, logits, mask) through pclseg_forward_raw."""
+  n, h, w, _ = raw.shape
+  model.micro_batch = micro_batch
+  eng = model.engine(h, w, flags)
+  preds = np.empty((n, h, w), np.int32)
+  logits = np.empty((n, h, w, model.NUM_CLASS), np.float32)
+  mask = np.empty((n, h, w), np.uint8)
+  eng.forward_raw(np.ascontiguousarray(raw), n, preds, None, logits, mask, mem=E.MEM_HOST)
+  return preds, logits, mask.astype(bool), eng
+
+
+def check_against(preds, logits, mask, gold_logits, gold_preds, gold_margin, none_index):
+  err = np.abs(logits - gold_logits).max()
+  assert err <= LOGIT_TOL, "max |logit - oracle| = %g" % err
+  assert (preds[~mask] == none_index).all()
+  decided = gold_margin > MARGIN
+  assert np.array_equal(preds[decided], gold_preds[decided])
+  return err
+
+
+@pytest.mark.parametrize("name,model_name,config_name", CASES, ids=[c[0] for c in CASES])
+def test_golden(cuda, name, model_name, config_name):
+  g = np.load(os.path.join(GOLDEN, "model_%s.npz" % name))
+  mc, model = P.load_model_config(model_name, config_name)
+  model.init_weights(4321)
+  preds, logits, mask, _ = run_engine(model, g["raw"])
+  assert np.array_equal(mask, g["mask"])
+  check_against(preds, logits, mask, g["logits"], g["preds"], g["margin"], mc.CLASSES.index("None"))
+
+
+@pytest.mark.parametrize("model_name,config_name,h,w", [
+  ("squeezesegv2", "squeezesegv2", 32, 240), ("darknet21", "darknet21", 32, 64)])
+def test_every_intermediate_matches_oracle(cuda, model_name, config_name, h, w):
+  """Layer-by-layer comparison (engine built with KEEP_ACTIVATIONS)."""
+  mc, model = P.load_model_config(model_name, config_name, height=h, width=w)
+  model.init_weights(4321)
+  raw = synthetic_scans(2, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.8, seed=99)
+  preds, logits, mask, eng = run_engine(model, raw, flags=E.FLAG_KEEP_ACTIVATIONS)
+  lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  taps = {}
+  O.forward(model.arch_name(), model.weights, lidar, omask, mc.CLASSES.index("None"),
+            num_layers=mc.get("NUM_LAYERS"), dtype=np.float64, taps=taps)
+  names = [t[0] for t in eng.tensors()]
+  report = []
+  for tap, want in taps.items():
+    if tap == "logits" or tap not in names:
+      continue
+    got = eng.read_tensor(names.index(tap))
+    report.append((tap, float(np.abs(got - want).max()), float(np.abs(want).max())))
+  bad = [r for r in report if r[1] > 1e-4 * max(1.0, r[2])]
+  assert report and not bad, "first mismatching tensors: %s" % bad[:5]
+  assert np.abs(logits - taps["logits"]).max() <= LOGIT_TOL
+
+
+def test_micro_batch_invariance(cuda):
+  """Any split of the batch into micro-batches gives bit-identical outputs."""
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  raw = synthetic_scans(5, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=5)
+  ref = None
+  for mb in (1, 2, 5, 16):
+    model._drop_engines()
+    preds, logits, _, _ = run_engine(model, raw, micro_batch=mb)
+    if ref is None:
+      ref = (preds.copy(), logits.copy())
+    else:
+      assert np.array_equal(preds, ref[0]) and np.array_equal(logits, ref[1])
+
+
+def test_model_call_surface(cuda):
+  """probabilities, predictions = model([lidar, mask]) — host arrays and device tensors."""
+  import torch
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  raw = synthetic_scans(2, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=11)
+  lidar, mask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)   # float64, like inference.py
+  probabilities, predictions = model([lidar, mask])
+  assert predictions.numpy().dtype == np.int32 and predictions.shape == (2, 32, 240)
+  assert probabilities.numpy().shape == (2, 32, 240, 11)
+  assert np.allclose(probabilities.numpy().sum(-1), 1.0, atol=1e-5)
+  assert np.array_equal(np.where(mask, probabilities.numpy().argmax(-1), 10), predictions.numpy())
+  # raw entry point agrees with the reference-shaped one
+  assert np.array_equal(model.predict_raw(raw).numpy(), predictions.numpy())
+  # device tensors in -> device tensors out, same numbers
+  pt, pr = model([torch.from_numpy(lidar).cuda(), torch.from_numpy(mask).cuda()])
+  torch.cuda.synchronize()
+  assert pr.is_cuda and np.array_equal(pr.cpu().numpy(), predictions.numpy())
+  assert np.array_equal(pt.cpu().numpy(), probabilities.numpy())
+  with pytest.raises(ValueError):
+    model([lidar[:, :, :200], mask[:, :, :200]])          # W % 16 != 0
+
+
+def test_idempotent_and_deterministic(cuda):
+  mc, model = P.load_model_config("darknet21", "darknet21", height=32, width=64)
+  model.init_weights(4321)
+  raw = synthetic_scans(3, 32, 64, mc.INPUT_MEAN, mc.INPUT_STD, 0.8, seed=2)
+  a = run_engine(model, raw)
+  b = run_engine(model, raw)
+  assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
