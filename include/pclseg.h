@@ -58,6 +58,17 @@ typedef enum pclseg_mem { PCLSEG_MEM_HOST = 0, PCLSEG_MEM_DEVICE = 1 } pclseg_me
 /* desc.flags */
 #define PCLSEG_FLAG_KEEP_ACTIVATIONS 1u /* debug: no workspace aliasing, so every
                                            intermediate can be read back after a forward */
+#define PCLSEG_FLAG_EXACT_F32 2u        /* run every convolution on the f32-input matrix cores
+                                           (bit-exact float32 products) instead of the default
+                                           split-f16 products (see pclseg_math) */
+
+/* Arithmetic of the convolutions.  Activations, accumulation and all outputs are float32 in
+ * both modes.
+ *   PCLSEG_MATH_F16X3: each float32 operand v is split hi = f16(v), lo = f16(v - hi) and a
+ *     product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (22-bit operands; logits
+ *     within ~1e-5 of the float64 oracle).  Default.  Requires |activation| < 65504.
+ *   PCLSEG_MATH_F32: v_mfma_f32_16x16x4_f32, exact float32 products. */
+typedef enum pclseg_math { PCLSEG_MATH_F16X3 = 0, PCLSEG_MATH_F32 = 1 } pclseg_math;
 
 /* Everything the forward pass reads from a reference config (configs/ *.py: ZENITH_LEVEL,
  * AZIMUTH_LEVEL, NUM_CLASS, CLASSES.index("None"), INPUT_MEAN, INPUT_STD, OUTPUT_STRIDE). */
@@ -161,18 +172,18 @@ int pclseg_op_normalize(const float* scans, int n, int h, int w, const double me
 /* Conv2D SAME, strides (1, stride_w), kernel (kh,kw,Cin,Cout) host pointer, optional bias and
  * BatchNorm (host pointers, NULL = absent), activation 0 none / 1 relu / 2 leaky(0.1) /
  * 3 sigmoid, optional residual added after the activation.  x, residual, y: device, NHWC;
- * Cin and Cout multiples of 4. */
+ * Cin and Cout multiples of 4.  math: pclseg_math. */
 int pclseg_op_conv2d(const float* x, int n, int h, int w, int cin, const float* kernel, int kh,
                      int kw, int cout, int stride_w, const float* bias, const float* bn_gamma,
                      const float* bn_beta, const float* bn_mean, const float* bn_var, int act,
-                     const float* residual, float* y);
+                     const float* residual, float* y, int math);
 
 /* Conv2DTranspose kernel (1,4), strides (1,2), SAME: kernel (1,4,Cout,Cin) host pointer.
  * y [n,h,2w,Cout]. */
 int pclseg_op_conv2d_transpose(const float* x, int n, int h, int w, int cin, const float* kernel,
                                int cout, const float* bias, const float* bn_gamma,
                                const float* bn_beta, const float* bn_mean, const float* bn_var,
-                               int act, float* y);
+                               int act, float* y, int math);
 
 /* MaxPool k x k, strides (1, stride_w), SAME (padding never wins). C multiple of 4. */
 int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int stride_w, float* y);
@@ -181,7 +192,7 @@ int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int st
  * preds required; probs/logits optional device pointers. */
 int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int cin,
                    const float* kernel, const float* bias, int num_class, int none_index,
-                   int32_t* preds, float* probs, float* logits);
+                   int32_t* preds, float* probs, float* logits, int math);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,10 @@ struct pclseg_handle {
   bool finalized = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  float* d_params = nullptr;
+  float* d_w32 = nullptr;      // exact-f32 weight fragments (only with PCLSEG_FLAG_EXACT_F32)
+  _Float16* d_w16 = nullptr;   // split-f16 weight fragments
+  float* d_bias = nullptr;     // folded biases
+  bool exact = false;
   float* d_arena = nullptr;
   uint8_t* d_mask = nullptr;  // micro-batch mask when the caller gives none
   // host-mode staging (grown on demand)
@@ -68,123 +71,167 @@ int fail(pclseg_handle* h, int code, const std::string& msg) {
   } while (0)
 
 // ---- BatchNorm folding + fragment packing -------------------------------------------------
-// wpk[((t*nc16 + c16)*nctp + ct)*256 + lane*4 + j] = K[tap t][ci = 16*c16 + 4*(lane>>4) + j]
-//                                                     [co = 16*ct + (lane&15)] * bn_scale[co]
 struct FoldIn {
   const float* kernel = nullptr;  // Keras layout
   const float* bias = nullptr;
   const float* gamma = nullptr, *beta = nullptr, *mean = nullptr, *var = nullptr;
 };
 
-void pack_op(const Op& op, const FoldIn& f, float* wdst, float* bdst) {
-  const int taps = op.kh * op.kw;
-  const int cin = op.cin_k, cout = op.cout;
-  std::vector<double> scale(cout, 1.0), shift(cout, 0.0);
-  for (int co = 0; co < cout; ++co) {
-    double b = f.bias ? (double)f.bias[co] : 0.0;
+// BN(conv(x)+b) = conv(x)*scale + shift, evaluated in float64
+void fold_bn(const SubOp& su, const FoldIn& f, std::vector<double>* scale, std::vector<double>* shift) {
+  scale->assign(su.cout, 1.0);
+  shift->assign(su.cout, 0.0);
+  for (int co = 0; co < su.cout; ++co) {
+    const double b = f.bias ? (double)f.bias[co] : 0.0;
     if (f.gamma) {
       const double s = (double)f.gamma[co] / std::sqrt((double)f.var[co] + kBnEps);
-      scale[co] = s;
-      shift[co] = (b - (double)f.mean[co]) * s + (double)f.beta[co];
+      (*scale)[co] = s;
+      (*shift)[co] = (b - (double)f.mean[co]) * s + (double)f.beta[co];
     } else {
-      shift[co] = b;
+      (*shift)[co] = b;
     }
   }
-  for (int i = 0; i < op.nctp * 16; ++i) bdst[i] = i < cout ? (float)shift[i] : 0.0f;
-  for (int t = 0; t < taps; ++t) {
-    for (int c16 = 0; c16 < op.nc16; ++c16)
-      for (int ct = 0; ct < op.nctp; ++ct) {
-        float* blk = wdst + ((size_t)(t * op.nc16 + c16) * op.nctp + ct) * 256;
+}
+
+// folded weight of window tap t, input channel ci, output channel co
+inline double folded_w(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<double>& scale,
+                       int t, int ci, int co) {
+  if (ci >= op.cin_k || co >= su.cout) return 0.0;
+  const int kt = su.ktap[t];
+  const double k = su.deconv ? f.kernel[((size_t)kt * su.cout + co) * op.cin_k + ci]   // (1,4,Cout,Cin)
+                             : f.kernel[((size_t)kt * op.cin_k + ci) * su.cout + co];  // (kh,kw,Cin,Cout)
+  return k * scale[co];
+}
+
+void pack_bias(const SubOp& su, const std::vector<double>& shift, float* bdst) {
+  for (int i = 0; i < su.nctp * 16; ++i) bdst[i] = i < su.cout ? (float)shift[i] : 0.0f;
+}
+
+// exact mode: w32[((t*nc16 + c16)*nctp + ct)*256 + lane*4 + j]
+//   = W[tap t][ci = 16*c16 + 4*(lane>>4) + j][co = 16*ct + (lane&15)]
+void pack_w32(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<double>& scale, float* dst) {
+  const int taps = su.nkh * su.nkw, nc16 = (op.cin_t + 15) / 16;
+  for (int t = 0; t < taps; ++t)
+    for (int c16 = 0; c16 < nc16; ++c16)
+      for (int ct = 0; ct < su.nctp; ++ct) {
+        float* blk = dst + ((size_t)(t * nc16 + c16) * su.nctp + ct) * 256;
         for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 4; ++j) {
-            const int ci = c16 * 16 + 4 * (lane >> 4) + j;
-            const int co = ct * 16 + (lane & 15);
-            float v = 0.0f;
-            if (ci < cin && co < cout) {
-              double k;
-              if (op.kind == OP_DECONV) {
-                // Keras Conv2DTranspose kernel (1,4,Cout,Cin); o = 2i + k - 1:
-                //   even o = 2j:   x[j-1]*K[3] (tap 0, patch col j-1) + x[j]*K[1] (tap 1)
-                //   odd  o = 2j+1: x[j]*K[2]   (tap 0, patch col j)   + x[j+1]*K[0] (tap 1)
-                const int parity = op.sw;
-                const int kk = parity == 0 ? (t == 0 ? 3 : 1) : (t == 0 ? 2 : 0);
-                k = f.kernel[((size_t)kk * cout + co) * cin + ci];
-              } else {
-                k = f.kernel[((size_t)t * cin + ci) * cout + co];
-              }
-              v = (float)(k * scale[co]);
+          for (int j = 0; j < 4; ++j)
+            blk[lane * 4 + j] = (float)folded_w(op, su, f, scale, t, c16 * 16 + 4 * (lane >> 4) + j,
+                                                ct * 16 + (lane & 15));
+      }
+}
+
+// split-f16 mode: per LDS chunk, K-step s and 16-cout tile ct one 2-KiB block [hi|lo][lane][8];
+// lane group g = lane>>4 of step s owns the (tap, 8-channel group) pair kidx = 4s + g.
+void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<double>& scale, _Float16* dst) {
+  const int taps = su.nkh * su.nkw;
+  const int cin8 = (op.cin_t + 7) / 8, ck8_full = op.ck16 / 8;
+  const int steps_full = f16_steps_full(op, su), nchunks = f16_chunks(op);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int ck8 = std::min(ck8_full, cin8 - chunk * ck8_full);
+    const int nk = taps * ck8;
+    for (int s = 0; s < steps_full; ++s)
+      for (int ct = 0; ct < su.nctp; ++ct) {
+        _Float16* blk = dst + ((size_t)(chunk * steps_full + s) * su.nctp + ct) * 1024;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int kidx = 4 * s + (lane >> 4);
+          for (int j = 0; j < 8; ++j) {
+            float w = 0.0f;
+            if (kidx < nk) {
+              const int tap = kidx / ck8, c8 = kidx % ck8;
+              w = (float)folded_w(op, su, f, scale, tap, (chunk * ck8_full + c8) * 8 + j, ct * 16 + (lane & 15));
             }
-            blk[lane * 4 + j] = v;
+            const _Float16 hi = (_Float16)w;
+            blk[lane * 8 + j] = hi;
+            blk[512 + lane * 8 + j] = (_Float16)(w - (float)hi);
           }
+        }
       }
   }
 }
 
 // ---- launch helpers -------------------------------------------------------------------------
-struct ConvGeom {
-  int N, H, Win;  // input tensor
-};
-
-template <bool HEAD>
+template <bool HEAD, bool F16>
 hipError_t launch_conv_nt(int nt, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
   switch (nt) {
-    case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, HEAD>), grid, dim3(kConvThreads), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, HEAD>), grid, dim3(kConvThreads), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, HEAD>), grid, dim3(kConvThreads), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((conv_mfma_kernel<4, HEAD>), grid, dim3(kConvThreads), lds, s, a); break;
+    case 1: hipLaunchKernelGGL((conv_kernel<1, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_kernel<2, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((conv_kernel<3, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((conv_kernel<4, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-// Fill geometry fields of `a` (pointers and channel bookkeeping already set) and launch.
-hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, hipStream_t s) {
+// Fill the geometry of `a` (tensor pointers already set) from `op` and launch.
+// w32 / w16 / bias are the bases the sub-op offsets are relative to.
+hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const float* w32,
+                       const _Float16* w16, const float* bias, bool exact, hipStream_t s) {
   a.Cin = op.cin_t;
-  a.nc16 = op.nc16;
-  a.Cout = op.cout;
-  a.nctp = op.nctp;
-  a.act = op.act;
   a.res1_mul = op.res1_mul ? 1 : 0;
-  const bool flat = (op.kind == OP_CONV && op.kh == 1 && op.kw == 1 && op.sw == 1);
-  if (op.kind == OP_DECONV) {
-    a.KH = 1; a.KW = 2; a.sw = 1; a.pt = 0; a.pl = (op.sw == 0) ? 1 : 0;
-    a.ow_mul = 2; a.ow_off = op.sw;
-    a.N = N; a.H = H; a.Win = Win; a.Wconv = Win; a.Wout = 2 * Win;
-  } else {
-    int wo, pl, ho, pt;
-    same_pad(Win, op.kw, op.sw, &wo, &pl);
-    same_pad(H, op.kh, 1, &ho, &pt);
-    a.KH = op.kh; a.KW = op.kw; a.sw = op.sw; a.pt = pt; a.pl = pl;
-    a.ow_mul = 1; a.ow_off = 0;
-    if (flat) {
-      a.N = 1; a.H = 1; a.Win = N * H * Win; a.Wconv = a.Wout = a.Win;
-    } else {
-      a.N = N; a.H = H; a.Win = Win; a.Wconv = a.Wout = wo;
-    }
+  a.nsub = op.nsub;
+  a.CK = op.ck16;
+  int ny = 0;
+  for (int i = 0; i < op.nsub; ++i) {
+    const SubOp& su = op.sub[i];
+    ConvSub& d = a.sub[i];
+    d.w32 = w32 ? w32 + su.w32_off : nullptr;
+    d.w16 = w16 ? w16 + su.w16_off : nullptr;
+    d.bias = bias + su.b_off;
+    d.Cout = su.cout;
+    d.nctp = su.nctp;
+    d.ny = su.nctp / op.nt;
+    d.co_off = su.co_off;
+    d.th0 = su.th0; d.tw0 = su.tw0; d.nkh = su.nkh; d.nkw = su.nkw;
+    d.ow_off = su.ow_off;
+    d.act = su.act;
+    ny += d.ny;
   }
-  if (flat) { a.TH = 1; a.SEGW = kSegsPerBlock; }
-  else { a.TH = kSegsPerBlock; a.SEGW = 1; }
-  a.PH = a.TH + a.KH - 1;
-  a.PW = (a.SEGW * 16 - 1) * a.sw + a.KW;
+  const bool flat = (op.kind == OP_CONV && op.pkh == 1 && op.pkw == 1 && op.sw == 1);
+  int wo, pl, ho, pt;
+  same_pad(Win, op.pkw, op.sw, &wo, &pl);
+  same_pad(H, op.pkh, 1, &ho, &pt);
+  a.sw = op.sw; a.pt = pt; a.pl = op.pl_fixed >= 0 ? op.pl_fixed : pl;
+  a.ow_mul = op.ow_mul;
+  if (flat) {
+    a.N = 1; a.H = 1; a.Win = N * H * Win; a.Wconv = a.Wout = a.Win;
+    a.TH = 1; a.SEGW = kSegsPerBlock;
+  } else {
+    a.N = N; a.H = H; a.Win = Win;
+    a.Wconv = op.ow_mul == 2 ? Win : wo;
+    a.Wout = op.ow_mul == 2 ? 2 * Win : wo;
+    a.TH = kSegsPerBlock; a.SEGW = 1;
+  }
+  a.PH = a.TH + op.pkh - 1;
+  a.PW = (a.SEGW * 16 - 1) * a.sw + op.pkw;
   a.tilesH = (a.H + a.TH - 1) / a.TH;
   a.tilesW = (a.Wconv + a.SEGW * 16 - 1) / (a.SEGW * 16);
-  const int cinp = a.nc16 * 16;
-  const int CS = (cinp < kChunk ? cinp : kChunk) + 4;
-  const size_t lds = (size_t)a.PH * a.PW * CS * sizeof(float);
-  dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)(a.nctp / op.nt));
-  if (op.kind == OP_HEAD) return launch_conv_nt<true>(op.nt, grid, lds, s, a);
-  return launch_conv_nt<false>(op.nt, grid, lds, s, a);
+  size_t lds;
+  if (exact) {
+    const int cinp = ((op.cin_t + 15) / 16) * 16;
+    lds = (size_t)a.PH * a.PW * (std::min(cinp, kChunk32) + kPadF32) * sizeof(float);
+  } else {
+    const int cin8 = (op.cin_t + 7) / 8;
+    lds = (size_t)2 * a.PH * a.PW * (std::min(cin8 * 8, op.ck16) + kPadF16) * sizeof(_Float16);
+  }
+  dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)ny);
+  if (op.kind == OP_HEAD)
+    return exact ? launch_conv_nt<true, false>(op.nt, grid, lds, s, a)
+                 : launch_conv_nt<true, true>(op.nt, grid, lds, s, a);
+  return exact ? launch_conv_nt<false, false>(op.nt, grid, lds, s, a)
+               : launch_conv_nt<false, true>(op.nt, grid, lds, s, a);
 }
 
-hipError_t launch_pool(const float* in, float* out, int N, int H, int Win, int C, int k, int sw,
-                       hipStream_t s) {
+hipError_t launch_pool(const float* in, float* out, int N, int H, int Win, int C, int kh, int kw,
+                       int sw, hipStream_t s) {
   int wo, pl, ho, pt;
-  same_pad(Win, k, sw, &wo, &pl);
-  same_pad(H, k, 1, &ho, &pt);
+  same_pad(Win, kw, sw, &wo, &pl);
+  same_pad(H, kh, 1, &ho, &pt);
   const size_t total = (size_t)N * H * wo * (C / 4);
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, in, out, N, H, Win, wo, C, k, sw,
-                     pt, pl);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, in, out, N, H, Win, wo, C, kh, kw,
+                     sw, pt, pl);
   return hipGetLastError();
 }
 
@@ -204,20 +251,17 @@ int ensure(pclseg_handle* h, void** p, size_t* have, size_t need) {
 int run_ops(pclseg_handle* h, int cnt, const uint8_t* mask, int32_t* preds, float* probs,
             float* logits) {
   const Graph& g = h->g;
-  const float* P = h->d_params;
   for (const Op& op : g.ops) {
     const TensorInfo& ti = g.tensors[op.in];
     const float* in = h->d_arena + ti.offset;
     if (op.kind == OP_POOL) {
       float* out = h->d_arena + g.tensors[op.out].offset;
-      HIP_TRY(h, launch_pool(in, out, cnt, ti.H, ti.W, ti.C, op.kh, op.sw, h->stream));
+      HIP_TRY(h, launch_pool(in, out, cnt, ti.H, ti.W, ti.C, op.pool_kh, op.pool_kw, op.sw, h->stream));
       continue;
     }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in;
-    a.wpk = P + op.w_off;
-    a.bias = P + op.b_off;
     if (op.kind == OP_HEAD) {
       a.mask = mask;
       a.preds = preds;
@@ -228,11 +272,10 @@ int run_ops(pclseg_handle* h, int cnt, const uint8_t* mask, int32_t* preds, floa
       const TensorInfo& to = g.tensors[op.out];
       a.out = h->d_arena + to.offset;
       a.out_C = to.C;
-      a.co_off = op.co_off;
       if (op.res1 >= 0) { a.res1 = h->d_arena + g.tensors[op.res1].offset; a.res1_C = g.tensors[op.res1].C; }
       if (op.res2 >= 0) { a.res2 = h->d_arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
     }
-    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->stream));
+    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, h->exact, h->stream));
   }
   return PCLSEG_OK;
 }
@@ -313,28 +356,44 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
   return PCLSEG_OK;
 }
 
-// geometry of a stand-alone op (single-operator entry points)
-void op_geometry(Op* op) {
-  op->nc16 = (op->cin_t + 15) / 16;
-  const int nct = (op->cout + 15) / 16;
-  op->nt = (op->kind == OP_HEAD) ? nct : choose_nt(nct);
-  op->nctp = ((nct + op->nt - 1) / op->nt) * op->nt;
-}
-
 struct DevBuf {
-  float* p = nullptr;
+  void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
-// pack + upload the parameters of one stand-alone op; w at dev.p, bias at dev.p + nw
-int upload_op(const Op& op, const FoldIn& f, DevBuf* dev, size_t* nw_out) {
-  const size_t nw = (size_t)op.kh * op.kw * op.nc16 * op.nctp * 256;
-  const size_t nb = (size_t)op.nctp * 16;
-  std::vector<float> host(nw + nb);
-  pack_op(op, f, host.data(), host.data() + nw);
-  HIP_TRY(nullptr, hipMalloc((void**)&dev->p, (nw + nb) * sizeof(float)));
-  HIP_TRY(nullptr, hipMemcpy(dev->p, host.data(), (nw + nb) * sizeof(float), hipMemcpyHostToDevice));
-  *nw_out = nw;
+// pack + upload the parameters of one stand-alone op and launch it on the default stream
+int run_single_op(Op* op, const FoldIn* folds, int n, int h, int w, ConvArgs a, int math) {
+  if (math != PCLSEG_MATH_F16X3 && math != PCLSEG_MATH_F32)
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, fmt("unknown math mode %d", math));
+  const bool exact = (math == PCLSEG_MATH_F32);
+  op_geometry(op);
+  size_t nw32 = 0, nw16 = 0, nb = 0;
+  for (int i = 0; i < op->nsub; ++i) {
+    SubOp& su = op->sub[i];
+    su.w32_off = nw32; nw32 += sub_w32_floats(*op, su);
+    su.w16_off = nw16; nw16 += sub_w16_halfs(*op, su);
+    su.b_off = nb; nb += (size_t)su.nctp * 16;
+  }
+  std::vector<float> hb(nb), hw32(exact ? nw32 : 0);
+  std::vector<_Float16> hw16(exact ? 0 : nw16);
+  for (int i = 0; i < op->nsub; ++i) {
+    const SubOp& su = op->sub[i];
+    std::vector<double> scale, shift;
+    fold_bn(su, folds[i], &scale, &shift);
+    pack_bias(su, shift, hb.data() + su.b_off);
+    if (exact) pack_w32(*op, su, folds[i], scale, hw32.data() + su.w32_off);
+    else pack_w16(*op, su, folds[i], scale, hw16.data() + su.w16_off);
+  }
+  DevBuf dw, db;
+  const size_t wbytes = exact ? nw32 * sizeof(float) : nw16 * sizeof(_Float16);
+  HIP_TRY(nullptr, hipMalloc(&dw.p, wbytes));
+  HIP_TRY(nullptr, hipMalloc(&db.p, nb * sizeof(float)));
+  HIP_TRY(nullptr, hipMemcpy(dw.p, exact ? (const void*)hw32.data() : (const void*)hw16.data(), wbytes,
+                             hipMemcpyHostToDevice));
+  HIP_TRY(nullptr, hipMemcpy(db.p, hb.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(nullptr, launch_conv(*op, n, h, w, a, exact ? (const float*)dw.p : nullptr,
+                               exact ? nullptr : (const _Float16*)dw.p, (const float*)db.p, exact, nullptr));
+  HIP_TRY(nullptr, hipDeviceSynchronize());
   return PCLSEG_OK;
 }
 
@@ -363,7 +422,8 @@ int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out) {
   out->alg_macs_per_scan = g.alg_macs;
   out->alg_bytes_per_scan = g.alg_bytes;
   out->workspace_bytes = g.arena_floats * (int64_t)sizeof(float);
-  out->packed_weight_bytes = g.packed_floats * (int64_t)sizeof(float);
+  const bool exact = (desc->flags & PCLSEG_FLAG_EXACT_F32) != 0;
+  out->packed_weight_bytes = (exact ? g.packed32_floats * 4 : g.packed16_halfs * 2) + g.packed_bias_floats * 4;
   return PCLSEG_OK;
 }
 
@@ -401,7 +461,11 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
   const size_t mask_bytes = (size_t)h->g.micro_batch * desc->height * desc->width;
   if ((e = hipMalloc((void**)&h->d_mask, mask_bytes)) != hipSuccess)
     return bail(PCLSEG_ERR_HIP, fmt("hipMalloc(mask): %s", hipGetErrorString(e)));
-  if ((e = hipMalloc((void**)&h->d_params, (size_t)h->g.packed_floats * sizeof(float))) != hipSuccess)
+  h->exact = (desc->flags & PCLSEG_FLAG_EXACT_F32) != 0;
+  if (h->exact) e = hipMalloc((void**)&h->d_w32, (size_t)h->g.packed32_floats * sizeof(float));
+  else e = hipMalloc((void**)&h->d_w16, (size_t)h->g.packed16_halfs * sizeof(_Float16));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, (size_t)h->g.packed_bias_floats * sizeof(float));
+  if (e != hipSuccess)
     return bail(e == hipErrorOutOfMemory ? PCLSEG_ERR_OOM : PCLSEG_ERR_HIP,
                 fmt("hipMalloc(parameters): %s", hipGetErrorString(e)));
   *out = h;
@@ -410,8 +474,8 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
 
 int pclseg_destroy(pclseg_handle* h) {
   if (!h) return PCLSEG_OK;
-  if (h->d_arena || h->d_params) (void)hipSetDevice(h->device);
-  void* bufs[] = {h->d_arena, h->d_params, h->d_mask, h->d_stage_in, h->d_stage_mask,
+  if (h->d_arena || h->d_bias) (void)hipSetDevice(h->device);
+  void* bufs[] = {h->d_arena, h->d_w32, h->d_w16, h->d_bias, h->d_mask, h->d_stage_in, h->d_stage_mask,
                   h->d_stage_preds, h->d_stage_probs, h->d_stage_logits};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
@@ -464,24 +528,35 @@ int pclseg_finalize(pclseg_handle* h) {
     auto it = h->g.weight_index.find(name);
     return it == h->g.weight_index.end() ? nullptr : h->host_w[it->second].data();
   };
-  std::vector<float> blob((size_t)h->g.packed_floats, 0.0f);
+  std::vector<float> w32(h->exact ? (size_t)h->g.packed32_floats : 0, 0.0f);
+  std::vector<_Float16> w16(h->exact ? 0 : (size_t)h->g.packed16_halfs, (_Float16)0.0f);
+  std::vector<float> bias((size_t)h->g.packed_bias_floats, 0.0f);
   for (const Op& op : h->g.ops) {
     if (op.kind == OP_POOL) continue;
-    FoldIn f;
-    f.kernel = W(op.name + "/kernel");
-    f.bias = op.has_bias ? W(op.name + "/bias") : nullptr;
-    if (!op.bn.empty()) {
-      f.gamma = W(op.bn + "/gamma");
-      f.beta = W(op.bn + "/beta");
-      f.mean = W(op.bn + "/moving_mean");
-      f.var = W(op.bn + "/moving_variance");
+    for (int i = 0; i < op.nsub; ++i) {
+      const SubOp& su = op.sub[i];
+      FoldIn f;
+      f.kernel = W(su.name + "/kernel");
+      f.bias = su.has_bias ? W(su.name + "/bias") : nullptr;
+      if (!su.bn.empty()) {
+        f.gamma = W(su.bn + "/gamma");
+        f.beta = W(su.bn + "/beta");
+        f.mean = W(su.bn + "/moving_mean");
+        f.var = W(su.bn + "/moving_variance");
+      }
+      if (!f.kernel || (su.has_bias && !f.bias) || (!su.bn.empty() && !(f.gamma && f.beta && f.mean && f.var)))
+        return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", su.name.c_str()));
+      std::vector<double> scale, shift;
+      fold_bn(su, f, &scale, &shift);
+      pack_bias(su, shift, bias.data() + su.b_off);
+      if (h->exact) pack_w32(op, su, f, scale, w32.data() + su.w32_off);
+      else pack_w16(op, su, f, scale, w16.data() + su.w16_off);
     }
-    if (!f.kernel || (op.has_bias && !f.bias) || (!op.bn.empty() && !(f.gamma && f.beta && f.mean && f.var)))
-      return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", op.name.c_str()));
-    pack_op(op, f, blob.data() + op.w_off, blob.data() + op.b_off);
   }
   HIP_TRY(h, hipSetDevice(h->device));
-  HIP_TRY(h, hipMemcpy(h->d_params, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (h->exact) HIP_TRY(h, hipMemcpy(h->d_w32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
+  else HIP_TRY(h, hipMemcpy(h->d_w16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   h->finalized = true;
   // the Keras-layout copies are no longer needed
   for (auto& v : h->host_w) std::vector<float>().swap(v);
@@ -552,7 +627,7 @@ int pclseg_op_normalize(const float* scans, int n, int h, int w, const double me
 int pclseg_op_conv2d(const float* x, int n, int h, int w, int cin, const float* kernel, int kh, int kw,
                      int cout, int stride_w, const float* bias, const float* bn_gamma,
                      const float* bn_beta, const float* bn_mean, const float* bn_var, int act,
-                     const float* residual, float* y) {
+                     const float* residual, float* y, int math) {
   if (!x || !kernel || !y || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_conv2d");
   if (cin % 4 || cout % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "Cin and Cout must be multiples of 4");
@@ -561,69 +636,73 @@ int pclseg_op_conv2d(const float* x, int n, int h, int w, int cin, const float* 
   Op op;
   op.kind = OP_CONV;
   op.cin_t = op.cin_k = cin;
-  op.cout = cout;
-  op.kh = kh; op.kw = kw; op.sw = stride_w;
-  op.act = act;
-  op_geometry(&op);
+  op.pkh = kh; op.pkw = kw; op.sw = stride_w;
+  op.sub[0].cout = cout;
+  op.sub[0].nkh = kh; op.sub[0].nkw = kw;
+  op.sub[0].act = act;
   FoldIn f;
   f.kernel = kernel; f.bias = bias;
   f.gamma = bn_gamma; f.beta = bn_beta; f.mean = bn_mean; f.var = bn_var;
-  DevBuf dev;
-  size_t nw;
-  int rc = upload_op(op, f, &dev, &nw);
-  if (rc) return rc;
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = x; a.wpk = dev.p; a.bias = dev.p + nw; a.out = y; a.out_C = cout;
+  a.in = x; a.out = y; a.out_C = cout;
   if (residual) { a.res1 = residual; a.res1_C = cout; }
-  HIP_TRY(nullptr, launch_conv(op, n, h, w, a, nullptr));
-  HIP_TRY(nullptr, hipDeviceSynchronize());
-  return PCLSEG_OK;
+  return run_single_op(&op, &f, n, h, w, a, math);
 }
 
 int pclseg_op_conv2d_transpose(const float* x, int n, int h, int w, int cin, const float* kernel,
                                int cout, const float* bias, const float* bn_gamma,
                                const float* bn_beta, const float* bn_mean, const float* bn_var,
-                               int act, float* y) {
+                               int act, float* y, int math) {
   if (!x || !kernel || !y || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_conv2d_transpose");
   if (cin % 4 || cout % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "Cin and Cout must be multiples of 4");
+  if (act < 0 || act > 3) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "unsupported activation");
+  Op op;
+  op.kind = OP_CONV;
+  op.cin_t = op.cin_k = cin;
+  op.pkh = 1; op.pkw = 3; op.sw = 1; op.pl_fixed = 1; op.ow_mul = 2;
+  op.nsub = 2;
+  FoldIn f[2];
   for (int parity = 0; parity < 2; ++parity) {
-    Op op;
-    op.kind = OP_DECONV;
-    op.cin_t = op.cin_k = cin;
-    op.cout = cout;
-    op.kh = 1; op.kw = 2; op.sw = parity;
-    op.act = act;
-    op_geometry(&op);
-    FoldIn f;
-    f.kernel = kernel; f.bias = bias;
-    f.gamma = bn_gamma; f.beta = bn_beta; f.mean = bn_mean; f.var = bn_var;
-    DevBuf dev;
-    size_t nw;
-    int rc = upload_op(op, f, &dev, &nw);
-    if (rc) return rc;
-    ConvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = x; a.wpk = dev.p; a.bias = dev.p + nw; a.out = y; a.out_C = cout;
-    HIP_TRY(nullptr, launch_conv(op, n, h, w, a, nullptr));
-    HIP_TRY(nullptr, hipDeviceSynchronize());
+    SubOp& s = op.sub[parity];
+    s.deconv = true;
+    s.cout = cout;
+    s.nkh = 1; s.nkw = 2; s.tw0 = parity;
+    s.ktap[0] = parity == 0 ? 3 : 2;
+    s.ktap[1] = parity == 0 ? 1 : 0;
+    s.ow_off = parity;
+    s.act = act;
+    f[parity].kernel = kernel; f[parity].bias = bias;
+    f[parity].gamma = bn_gamma; f[parity].beta = bn_beta; f[parity].mean = bn_mean; f[parity].var = bn_var;
   }
-  return PCLSEG_OK;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = x; a.out = y; a.out_C = cout;
+  return run_single_op(&op, f, n, h, w, a, math);
 }
 
 int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int stride_w, float* y) {
   if (!x || !y || n <= 0 || h <= 0 || w <= 0 || k <= 0 || (stride_w != 1 && stride_w != 2))
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_max_pool");
   if (c % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "C must be a multiple of 4");
-  HIP_TRY(nullptr, launch_pool(x, y, n, h, w, c, k, stride_w, nullptr));
+  if (k > 3 && stride_w == 1) {
+    // separable, exactly as the graph runs CAM's 7x7 pool: rows (1xk) then columns (kx1)
+    DevBuf tmp;
+    HIP_TRY(nullptr, hipMalloc(&tmp.p, (size_t)n * h * w * c * sizeof(float)));
+    HIP_TRY(nullptr, launch_pool(x, (float*)tmp.p, n, h, w, c, 1, k, 1, nullptr));
+    HIP_TRY(nullptr, launch_pool((const float*)tmp.p, y, n, h, w, c, k, 1, 1, nullptr));
+    HIP_TRY(nullptr, hipDeviceSynchronize());
+    return PCLSEG_OK;
+  }
+  HIP_TRY(nullptr, launch_pool(x, y, n, h, w, c, k, k, stride_w, nullptr));
   HIP_TRY(nullptr, hipDeviceSynchronize());
   return PCLSEG_OK;
 }
 
 int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int cin,
                    const float* kernel, const float* bias, int num_class, int none_index,
-                   int32_t* preds, float* probs, float* logits) {
+                   int32_t* preds, float* probs, float* logits, int math) {
   if (!x || !mask || !kernel || !bias || !preds || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_head");
   if (cin % 4 || num_class < 2 || num_class > 64)
@@ -631,22 +710,16 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
   Op op;
   op.kind = OP_HEAD;
   op.cin_t = op.cin_k = cin;
-  op.cout = num_class;
-  op.kh = op.kw = 3; op.sw = 1;
-  op_geometry(&op);
+  op.pkh = op.pkw = 3; op.sw = 1;
+  op.sub[0].cout = num_class;
+  op.sub[0].nkh = op.sub[0].nkw = 3;
   FoldIn f;
   f.kernel = kernel; f.bias = bias;
-  DevBuf dev;
-  size_t nw;
-  int rc = upload_op(op, f, &dev, &nw);
-  if (rc) return rc;
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.in = x; a.wpk = dev.p; a.bias = dev.p + nw;
+  a.in = x;
   a.mask = mask; a.preds = preds; a.probs = probs; a.logits = logits; a.none_index = none_index;
-  HIP_TRY(nullptr, launch_conv(op, n, h, w, a, nullptr));
-  HIP_TRY(nullptr, hipDeviceSynchronize());
-  return PCLSEG_OK;
+  return run_single_op(&op, &f, n, h, w, a, math);
 }
 
 }  // extern "C"

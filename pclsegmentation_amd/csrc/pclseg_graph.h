@@ -20,7 +20,7 @@
 
 namespace pclseg {
 
-enum OpKind { OP_CONV = 0, OP_DECONV = 1, OP_POOL = 2, OP_HEAD = 3 };
+enum OpKind { OP_CONV = 0, OP_POOL = 2, OP_HEAD = 3 };
 
 struct WeightInfo {
   std::string name;
@@ -41,22 +41,38 @@ struct TensorInfo {
   int64_t scan_floats() const { return (int64_t)H * W * C; }
 };
 
+// One Keras layer's share of a launch: a window of taps inside the staged input patch.
+struct SubOp {
+  std::string name;  // Keras layer path, e.g. "fire2/expand3x3"
+  std::string bn;    // Keras BatchNormalization path, "" = none
+  bool has_bias = true;
+  bool deconv = false;    // Keras kernel layout (1,4,Cout,Cin) instead of (kh,kw,Cin,Cout)
+  int cout = 0, co_off = 0;
+  int th0 = 0, tw0 = 0, nkh = 1, nkw = 1;  // tap window inside the patch
+  int ktap[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};  // window tap -> tap index of the Keras kernel
+  int ow_off = 0;
+  int act = 0;
+  // packed parameters (offsets into the device blobs; w16 in halfs)
+  int nctp = 0;
+  int64_t w32_off = 0, w16_off = 0, b_off = 0;
+};
+
 struct Op {
   int kind = OP_CONV;
-  std::string name;    // Keras layer path, e.g. "fire2/expand3x3"
-  std::string bn;      // Keras BatchNormalization path, "" = none
-  bool has_bias = true;
   int in = -1, out = -1, res1 = -1, res2 = -1;
   bool res1_mul = false;
-  int cin_t = 0;       // channels of the input tensor (8 for the zero-padded network input)
-  int cin_k = 0;       // Cin of the Keras kernel (6 for the network input)
-  int cout = 0;
-  int kh = 1, kw = 1, sw = 1;
-  int act = 0;
-  int co_off = 0;
-  // packed parameters: float offsets into the device parameter blob
-  int64_t w_off = 0, b_off = 0;
-  int nc16 = 0, nctp = 0, nt = 0;
+  int cin_t = 0;  // channels of the input tensor (8 for the zero-padded network input)
+  int cin_k = 0;  // Cin of the Keras kernel (6 for the network input)
+  int pkh = 1, pkw = 1;  // tap extent of the staged patch
+  int sw = 1;            // W stride of the convolution
+  int pl_fixed = -1;     // >= 0: left padding of the patch (transposed conv), else TF SAME
+  int ow_mul = 1;        // output column = j*ow_mul + sub.ow_off (2 for transposed conv)
+  int nsub = 1;
+  SubOp sub[2];
+  int nt = 1;            // 16-cout tiles per block (template parameter of the kernel)
+  int ck16 = 64;         // channels per LDS pass in split-f16 mode
+  int pool_kh = 1, pool_kw = 1;
+  std::string name() const { return sub[0].name; }
 };
 
 struct Graph {
@@ -68,7 +84,8 @@ struct Graph {
   std::map<std::string, int> weight_index;
   int t_input = -1;  // lidar8
   int64_t arena_floats = 0;  // per micro-batch
-  int64_t alg_macs = 0, alg_bytes = 0, num_params = 0, packed_floats = 0;
+  int64_t alg_macs = 0, alg_bytes = 0, num_params = 0;
+  int64_t packed32_floats = 0, packed16_halfs = 0, packed_bias_floats = 0;
   std::string error;
 };
 
@@ -84,6 +101,34 @@ inline int choose_nt(int nct) {
   if (nct % 2 == 0) return 2;
   if (nct == 1) return 1;
   return 4;
+}
+
+// Geometry of the packed parameters of one op (shared by the graph and the stand-alone ops).
+// LDS budget decides the split-f16 chunk: two planes of PH*PW*(CK+8) halfs must fit 64 KiB.
+inline void op_geometry(Op* op) {
+  if (op->kind == OP_POOL) return;
+  const int nct = (op->sub[0].cout + 15) / 16;
+  op->nt = (op->kind == OP_HEAD) ? nct : choose_nt(nct);
+  for (int i = 0; i < op->nsub; ++i) {
+    const int n = (op->sub[i].cout + 15) / 16;
+    op->sub[i].nctp = ((n + op->nt - 1) / op->nt) * op->nt;
+  }
+  const bool flat = (op->kind == OP_CONV && op->pkh == 1 && op->pkw == 1 && op->sw == 1);
+  const int TH = flat ? 1 : 8, SEGW = flat ? 8 : 1;
+  const int PH = TH + op->pkh - 1, PW = (SEGW * 16 - 1) * op->sw + op->pkw;
+  const int cin8 = (op->cin_t + 7) / 8;
+  op->ck16 = 64;
+  auto lds = [&](int ck) { return (int64_t)2 * PH * PW * (std::min(cin8 * 8, ck) + 8) * 2; };
+  if (lds(64) > 64 * 1024) op->ck16 = 32;
+}
+
+inline int64_t sub_w32_floats(const Op& op, const SubOp& s) {
+  return (int64_t)s.nkh * s.nkw * ((op.cin_t + 15) / 16) * s.nctp * 256;
+}
+inline int f16_steps_full(const Op& op, const SubOp& s) { return (s.nkh * s.nkw * (op.ck16 / 8) + 3) / 4; }
+inline int f16_chunks(const Op& op) { return ((op.cin_t + 7) / 8 + op.ck16 / 8 - 1) / (op.ck16 / 8); }
+inline int64_t sub_w16_halfs(const Op& op, const SubOp& s) {
+  return (int64_t)f16_chunks(op) * f16_steps_full(op, s) * s.nctp * 1024;
 }
 
 class GraphBuilder {
@@ -123,6 +168,24 @@ class GraphBuilder {
     ti.last_op = std::max(ti.last_op, op);
   }
 
+  // declare the Keras tensors of a Conv2D layer and return its SubOp (full kh x kw window)
+  SubOp conv_sub(const std::string& name, int kh, int kw, int cin_k, int cout, bool bias,
+                 const std::string& bn, int act, int co_off) {
+    SubOp s;
+    s.name = name;
+    s.bn = bn;
+    s.has_bias = bias;
+    s.cout = cout;
+    s.co_off = co_off;
+    s.nkh = kh;
+    s.nkw = kw;
+    s.act = act;
+    add_weight(name + "/kernel", {kh, kw, cin_k, cout});
+    if (bias) add_weight(name + "/bias", {cout});
+    if (!bn.empty()) add_bn(bn, cout);
+    return s;
+  }
+
   // Conv2D SAME (+bias) (+BN) (+act), optional residuals, optional channel-slice output.
   // `out` < 0 creates the output tensor; returns the output tensor id.
   int conv(const std::string& name, int in, int kh, int kw, int cout, int sw, bool bias,
@@ -131,35 +194,48 @@ class GraphBuilder {
     const TensorInfo ti = g_->tensors[in];
     Op op;
     op.kind = OP_CONV;
-    op.name = name;
-    op.bn = bn;
-    op.has_bias = bias;
     op.in = in;
     op.cin_t = ti.C;
     op.cin_k = cin_k < 0 ? ti.C : cin_k;
-    op.cout = cout;
-    op.kh = kh;
-    op.kw = kw;
+    op.pkh = kh;
+    op.pkw = kw;
     op.sw = sw;
-    op.act = act;
-    op.co_off = co_off;
     op.res1 = res1;
     op.res1_mul = res1_mul;
     op.res2 = res2;
+    op.sub[0] = conv_sub(name, kh, kw, op.cin_k, cout, bias, bn, act, co_off);
     int wo, pl;
     same_pad(ti.W, kw, sw, &wo, &pl);
     if (out < 0) out = tensor(name, ti.H, wo, cout);
     op.out = out;
-    // weights are declared once per Keras layer (a transposed conv is two ops)
-    add_weight(name + "/kernel", {kh, kw, op.cin_k, cout});
-    if (bias) add_weight(name + "/bias", {cout});
-    if (!bn.empty()) add_bn(bn, cout);
     g_->alg_macs += (int64_t)ti.H * wo * kh * kw * op.cin_k * cout;
     push(op);
     return out;
   }
 
-  // Conv2DTranspose (1,4)/(1,2) SAME (+bias) (+BN) (+act): two parity ops.
+  // FIRE / FIREUP expand stage: relu(bn(1x1)) || relu(bn(3x3)) over the same input, written to
+  // the two channel slices of `out` (tf.concat), one launch, one staged patch.
+  void expand_pair(const std::string& p, int in, int e1, int e3, int out, int skip) {
+    const TensorInfo ti = g_->tensors[in];
+    Op op;
+    op.kind = OP_CONV;
+    op.in = in;
+    op.out = out;
+    op.cin_t = op.cin_k = ti.C;
+    op.pkh = op.pkw = 3;
+    op.sw = 1;
+    op.res1 = skip;
+    op.nsub = 2;
+    op.sub[0] = conv_sub(p + "/expand1x1", 1, 1, ti.C, e1, true, p + "/expand1x1_bn", 1, 0);
+    op.sub[0].th0 = op.sub[0].tw0 = 1;  // centre tap of the 3x3 patch
+    op.sub[1] = conv_sub(p + "/expand3x3", 3, 3, ti.C, e3, true, p + "/expand3x3_bn", 1, e1);
+    g_->alg_macs += (int64_t)ti.H * ti.W * ti.C * (e1 + 9 * e3);
+    push(op);
+  }
+
+  // Conv2DTranspose (1,4)/(1,2) SAME (+bias) (+BN) (+act): o = 2i + k - 1, so
+  //   even o = 2j  : x[j-1]*K[3] + x[j]*K[1]      odd o = 2j+1 : x[j]*K[2] + x[j+1]*K[0]
+  // = two 2-tap sub-convs over the patch {x[j-1], x[j], x[j+1]}, one launch.
   int deconv(const std::string& name, int in, int cout, const std::string& bn, int act) {
     const TensorInfo ti = g_->tensors[in];
     int out = tensor(name, ti.H, ti.W * 2, cout);
@@ -167,54 +243,71 @@ class GraphBuilder {
     add_weight(name + "/bias", {cout});
     if (!bn.empty()) add_bn(bn, cout);
     g_->alg_macs += (int64_t)ti.H * ti.W * 4 * ti.C * cout;
+    Op op;
+    op.kind = OP_CONV;
+    op.in = in;
+    op.out = out;
+    op.cin_t = op.cin_k = ti.C;
+    op.pkh = 1;
+    op.pkw = 3;
+    op.sw = 1;
+    op.pl_fixed = 1;
+    op.ow_mul = 2;
+    op.nsub = 2;
     for (int parity = 0; parity < 2; ++parity) {
-      Op op;
-      op.kind = OP_DECONV;
-      op.name = name;
-      op.bn = bn;
-      op.has_bias = true;
-      op.in = in;
-      op.out = out;
-      op.cin_t = op.cin_k = ti.C;
-      op.cout = cout;
-      op.kh = 1;
-      op.kw = 2;
-      op.sw = parity;  // parity stored in sw for OP_DECONV
-      op.act = act;
-      push(op);
+      SubOp& s = op.sub[parity];
+      s.name = name;
+      s.bn = bn;
+      s.has_bias = true;
+      s.deconv = true;
+      s.cout = cout;
+      s.nkh = 1;
+      s.nkw = 2;
+      s.tw0 = parity;
+      s.ktap[0] = parity == 0 ? 3 : 2;
+      s.ktap[1] = parity == 0 ? 1 : 0;
+      s.ow_off = parity;
+      s.act = act;
     }
+    push(op);
     return out;
   }
 
+  // MaxPool SAME; k x k windows with k > 3 run as two separable passes (1xk then kx1).
   int pool(const std::string& name, int in, int k, int sw) {
     const TensorInfo ti = g_->tensors[in];
     int wo, pl;
     same_pad(ti.W, k, sw, &wo, &pl);
-    Op op;
-    op.kind = OP_POOL;
-    op.name = name;
-    op.in = in;
-    op.kh = op.kw = k;
-    op.sw = sw;
-    op.cin_t = op.cin_k = op.cout = ti.C;
-    op.out = tensor(name, ti.H, wo, ti.C);
-    push(op);
-    return op.out;
+    auto one = [&](const std::string& nm, int src, int kh, int kw, int s, int w_out) {
+      Op op;
+      op.kind = OP_POOL;
+      op.sub[0].name = nm;
+      op.in = src;
+      op.pool_kh = kh;
+      op.pool_kw = kw;
+      op.sw = s;
+      op.cin_t = op.cin_k = ti.C;
+      op.sub[0].cout = ti.C;
+      op.out = tensor(nm, ti.H, w_out, ti.C);
+      push(op);
+      return op.out;
+    };
+    if (k > 3 && sw == 1) {
+      const int rows = one(name + "/rows", in, 1, k, 1, ti.W);
+      return one(name, rows, k, 1, 1, ti.W);
+    }
+    return one(name, in, k, k, sw, wo);
   }
 
   void head(const std::string& name, int in, int num_class) {
     const TensorInfo ti = g_->tensors[in];
     Op op;
     op.kind = OP_HEAD;
-    op.name = name;
     op.in = in;
     op.cin_t = op.cin_k = ti.C;
-    op.cout = num_class;
-    op.kh = op.kw = 3;
+    op.pkh = op.pkw = 3;
     op.sw = 1;
-    op.has_bias = true;
-    add_weight(name + "/kernel", {3, 3, ti.C, num_class});
-    add_weight(name + "/bias", {num_class});
+    op.sub[0] = conv_sub(name, 3, 3, ti.C, num_class, true, "", 0, 0);
     g_->alg_macs += (int64_t)ti.H * ti.W * 9 * ti.C * num_class;
     push(op);
   }
@@ -261,8 +354,7 @@ inline void build_squeezesegv2(Graph* g) {
     int s = b.conv(p + "/squeeze", x, 1, 1, sq_c, 1, true, p + "/squeeze_bn", 1);
     if (up) s = b.deconv(p + "/upconv", s, sq_c, "", 1);  // ReLU, no BN (:194)
     const int out = b.tensor(p, g->tensors[s].H, g->tensors[s].W, e1 + e3);
-    b.conv(p + "/expand1x1", s, 1, 1, e1, 1, true, p + "/expand1x1_bn", 1, out, 0, skip);
-    b.conv(p + "/expand3x3", s, 3, 3, e3, 1, true, p + "/expand3x3_bn", 1, out, e1, skip);
+    b.expand_pair(p, s, e1, e3, out, skip);
     b.module_bytes(b.fl(x) + (skip >= 0 ? b.fl(skip) : 0), b.fl(out));
     return out;
   };
@@ -457,21 +549,20 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
   g->micro_batch = resolve_micro_batch(*d);
   if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) build_squeezesegv2(g);
   else build_darknet(g, d->arch == PCLSEG_ARCH_DARKNET21 ? 21 : 53);
-  // packed-parameter geometry
-  int64_t pf = 0;
+  // packed-parameter geometry: exact-f32 fragments, split-f16 fragments, biases
   for (Op& op : g->ops) {
     if (op.kind == OP_POOL) continue;
-    op.nc16 = (op.cin_t + 15) / 16;
-    const int nct = (op.cout + 15) / 16;
-    op.nt = (op.kind == OP_HEAD) ? nct : choose_nt(nct);
-    op.nctp = ((nct + op.nt - 1) / op.nt) * op.nt;
-    const int taps = op.kh * op.kw;
-    op.w_off = pf;
-    pf += (int64_t)taps * op.nc16 * op.nctp * 256;
-    op.b_off = pf;
-    pf += (int64_t)op.nctp * 16;
+    op_geometry(&op);
+    for (int i = 0; i < op.nsub; ++i) {
+      SubOp& su = op.sub[i];
+      su.w32_off = g->packed32_floats;
+      g->packed32_floats += sub_w32_floats(op, su);
+      su.w16_off = g->packed16_halfs;
+      g->packed16_halfs += sub_w16_halfs(op, su);
+      su.b_off = g->packed_bias_floats;
+      g->packed_bias_floats += (int64_t)su.nctp * 16;
+    }
   }
-  g->packed_floats = pf;
   plan_workspace(g);
   return PCLSEG_OK;
 }

@@ -3,20 +3,26 @@
 // Layout: every activation is float32 NHWC with C a multiple of 4, so one lane moves one
 // 16-byte channel quad and a run of pixels along W is one contiguous span in HBM.
 //
-// conv_mfma_kernel is the workhorse: an implicit-GEMM convolution on the f32-input matrix
-// cores (v_mfma_f32_16x16x4_f32 — exact float32, bit-identical to an fmaf chain), with the
-// input halo patch staged once per channel chunk in LDS and the (BatchNorm-folded) weights
-// streamed from L2 in a pre-packed per-lane fragment order.  It covers
+// conv_kernel is the workhorse: an implicit-GEMM convolution on the matrix cores with the
+// zero-padded input halo patch staged in LDS and the BatchNorm-folded weights streamed from L2
+// in a pre-packed per-lane fragment order.  Two arithmetic modes:
+//   F16X3 = false  v_mfma_f32_16x16x4_f32: exact float32 (bit-identical to an fmaf chain).
+//   F16X3 = true   v_mfma_f32_16x16x32_f16 on split operands: every float32 value v is carried
+//                  as hi = f16(v), lo = f16(v - hi) (22 significant bits) and a product is
+//                  hi*hi + hi*lo + lo*hi with float32 accumulation — float32-class accuracy
+//                  (|logit error| ~1e-5 through the whole network) at 3/16 of the f32 MFMA cost.
+// One launch covers
 //   Conv2D 3x3 / 1x1, strides (1,1) and (1,2), TF "SAME" padding      (SURVEY.md K2,K3,K4)
-//   Conv2DTranspose (1,4)/(1,2) as two 2-tap convs, one per output parity      (K5)
+//   Conv2DTranspose (1,4)/(1,2): both output parities as two 2-tap sub-convs     (K5)
+//   FIRE's expand1x1 || expand3x3 pair as two sub-convs over one staged patch
 //   fused epilogues: +bias(BN) -> relu / leaky(0.1) / sigmoid -> (*gate | +residual) -> +skip,
-//   writing into a channel slice of the destination (tf.concat for free)         (K8)
+//   written into a channel slice of the destination (tf.concat for free)         (K8)
 //   and the segmentation head: 3x3 conv -> [softmax] -> argmax -> mask            (K9)
 //
-// GEMM orientation: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].  With the 16x16x4 lane
-// maps (A: row = lane&15, k = lane>>4; B: k = lane>>4, col = lane&15; D: col = lane&15,
-// row = 4*(lane>>4)+reg) a lane ends up holding 4 CONSECUTIVE output channels of ONE pixel, so
-// the epilogue is 16-byte loads/stores along the channel axis.
+// GEMM orientation: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel].  With the 16x16 lane maps
+// (A: row = lane&15; B: col = lane&15; D: col = lane&15, row = 4*(lane>>4)+reg) a lane ends up
+// holding 4 CONSECUTIVE output channels of ONE pixel, so the epilogue is 16-byte loads/stores
+// along the channel axis.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,19 +30,34 @@
 namespace pclseg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
 
 constexpr int kConvThreads = 256;  // 4 waves, one per SIMD
 constexpr int kMT = 2;             // 16-pixel segments per wave
 constexpr int kSegsPerBlock = 4 * kMT;
-constexpr int kChunk = 32;         // input channels staged per LDS pass
+constexpr int kChunk32 = 32;       // input channels staged per LDS pass, exact-f32 mode
+constexpr int kPadF32 = 4;         // floats of per-pixel LDS padding (bank spread)
+constexpr int kPadF16 = 8;         // halfs of per-pixel LDS padding
+
+// A sub-convolution: a window of taps inside the staged patch, with its own weights / bias /
+// activation / destination channel slice / output column phase.
+struct ConvSub {
+  const float* w32;     // exact mode: [tap][c16][ct][lane][4] floats
+  const _Float16* w16;  // f16x3 mode: [chunk-step][ct][hi|lo][lane][8] halfs
+  const float* bias;    // [nctp*16]
+  int Cout, nctp, ny;   // ny = nctp / NT blocks along grid.y
+  int co_off;           // destination channel offset
+  int th0, tw0, nkh, nkw;  // tap window inside the patch
+  int ow_off;           // output column = j*ow_mul + ow_off
+  int act;
+};
 
 struct ConvArgs {
   const float* in;    // [N,H,Win,Cin]
-  const float* wpk;   // packed weights [tap][c16][ct][lane][4]
-  const float* bias;  // [nctp*16]
-  float* out;         // [N,H,Wout,out_C], written at channel offset co_off
+  float* out;         // [N,H,Wout,out_C]
   const float* res1;  // optional, [N,H,Wout,res1_C], read at co_off + co
   const float* res2;  // optional
   const uint8_t* mask;  // head only
@@ -44,11 +65,13 @@ struct ConvArgs {
   float* probs;         // head only, optional
   float* logits;        // head only, optional
   int N, H, Win, Wout, Wconv;
-  int Cin, nc16, Cout, nctp;
-  int out_C, co_off, res1_C, res2_C;
-  int KH, KW, sw, pt, pl, ow_mul, ow_off;
+  int Cin, out_C, res1_C, res2_C;
+  int sw, pt, pl, ow_mul;
   int TH, SEGW, PH, PW, tilesH, tilesW;
-  int act, res1_mul, none_index;
+  int res1_mul, none_index;
+  int CK;  // f16x3 mode: channels staged per LDS pass (32 or 64)
+  int nsub;
+  ConvSub sub[2];
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -60,9 +83,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int NT, bool HEAD>
-__global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(const ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int NT, bool HEAD, bool F16X3>
+__global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +99,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(const ConvArgs 
   const int n = tile / a.tilesH;
   const int h0 = thi * a.TH;
   const int w0 = twi * (a.SEGW * 16);
-  const int ct0 = blockIdx.y * NT;
+  const int by = blockIdx.y;
+  const int si = (a.nsub > 1 && by >= a.sub[0].ny) ? 1 : 0;
+  const ConvSub& S = a.sub[si];
+  const int ct0 = (by - (si ? a.sub[0].ny : 0)) * NT;
 
   f32x4 acc[kMT][NT];
 #pragma unroll
@@ -84,10 +110,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
     for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int cinp = a.nc16 * 16;
-  const int CS = (cinp < kChunk ? cinp : kChunk) + 4;  // floats per patch pixel (+4: bank spread)
   const float* in_n = a.in + (size_t)n * a.H * a.Win * a.Cin;
-  const int ntaps = a.KH * a.KW;
 
   // this wave's two segments: (row, column-segment) inside the tile
   int seg_r[kMT], seg_q[kMT];
@@ -98,90 +121,190 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(const ConvArgs 
     seg_q[m] = seg - seg_r[m] * a.SEGW;
   }
 
-  for (int c0 = 0; c0 < cinp; c0 += kChunk) {
-    const int ckp = (cinp - c0) < kChunk ? (cinp - c0) : kChunk;
-    const int cqn = ckp >> 2;
-    if (c0) __syncthreads();
-    // ---- stage the zero-padded input patch [PH][PW][ckp] into LDS
-    const int total = a.PH * a.PW * cqn;
-    for (int idx = tid; idx < total; idx += kConvThreads) {
-      const int cq = idx % cqn;
-      const int pix = idx / cqn;
-      const int pc = pix % a.PW;
-      const int pr = pix / a.PW;
-      const int h = h0 - a.pt + pr;
-      const int w = w0 * a.sw - a.pl + pc;
-      const int c = c0 + cq * 4;
-      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (h >= 0 && h < a.H && w >= 0 && w < a.Win && c < a.Cin)
-        v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)h * a.Win + w) * a.Cin + c);
-      *reinterpret_cast<f32x4*>(smem + (pr * a.PW + pc) * CS + cq * 4) = v;
-    }
-    __syncthreads();
-
-    // ---- matrix-core loop over taps x 16-channel sub-chunks
-    const int nsub = ckp >> 4;
-    for (int t = 0; t < ntaps; ++t) {
-      const int th = t / a.KW;
-      const int tw = t - th * a.KW;
-      for (int sub = 0; sub < nsub; ++sub) {
-        const int c16 = (c0 >> 4) + sub;
-        const float* wb = a.wpk + ((size_t)(t * a.nc16 + c16) * a.nctp + ct0) * 256 + lane * 4;
-        f32x4 wv[NT];
+  if constexpr (!F16X3) {
+    // ------------------------------------------------------------ exact float32 matrix cores
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    const int nc16 = (a.Cin + 15) >> 4;
+    const int cinp = nc16 * 16;
+    const int CS = (cinp < kChunk32 ? cinp : kChunk32) + kPadF32;  // floats per patch pixel
+    const int ntaps = S.nkh * S.nkw;
+    for (int c0 = 0; c0 < cinp; c0 += kChunk32) {
+      const int ckp = (cinp - c0) < kChunk32 ? (cinp - c0) : kChunk32;
+      const int cqn = ckp >> 2;
+      if (c0) __syncthreads();
+      const int total = a.PH * a.PW * cqn;
+      for (int idx = tid; idx < total; idx += kConvThreads) {
+        const int cq = idx % cqn;
+        const int pix = idx / cqn;
+        const int pc = pix % a.PW;
+        const int pr = pix / a.PW;
+        const int h = h0 - a.pt + pr;
+        const int w = w0 * a.sw - a.pl + pc;
+        const int c = c0 + cq * 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < a.H && w >= 0 && w < a.Win && c < a.Cin)
+          v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)h * a.Win + w) * a.Cin + c);
+        *reinterpret_cast<f32x4*>(smem + (pr * a.PW + pc) * CS + cq * 4) = v;
+      }
+      __syncthreads();
+      const int nsubk = ckp >> 4;
+      for (int t = 0; t < ntaps; ++t) {
+        const int ti = t / S.nkw;
+        const int th = S.th0 + ti;
+        const int tw = S.tw0 + (t - ti * S.nkw);
+        for (int sk = 0; sk < nsubk; ++sk) {
+          const int c16 = (c0 >> 4) + sk;
+          const float* wb = S.w32 + ((size_t)(t * nc16 + c16) * S.nctp + ct0) * 256 + lane * 4;
+          f32x4 wv[NT];
 #pragma unroll
-        for (int nn = 0; nn < NT; ++nn) wv[nn] = *reinterpret_cast<const f32x4*>(wb + nn * 256);
-        f32x4 xv[kMT];
+          for (int nn = 0; nn < NT; ++nn) wv[nn] = *reinterpret_cast<const f32x4*>(wb + nn * 256);
+          f32x4 xv[kMT];
+#pragma unroll
+          for (int m = 0; m < kMT; ++m) {
+            const int pcol = (seg_q[m] * 16 + p) * a.sw + tw;
+            const int prow = seg_r[m] + th;
+            xv[m] = *reinterpret_cast<const f32x4*>(smem + (prow * a.PW + pcol) * CS + sk * 16 + g * 4);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+              for (int nn = 0; nn < NT; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nn][j], xv[m][j], acc[m][nn], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    // ------------------------------------------------------------ split-f16 matrix cores
+    // LDS: two planes (hi, lo) of [PH][PW][CSh] halfs.  K runs over (tap, 8-channel group)
+    // pairs: lane group g of K-step s owns pair kidx = 4s + g, so taps with few channels
+    // (Cin = 16, 48) still fill the 32-deep MFMA.
+    _Float16* sm = reinterpret_cast<_Float16*>(smem_raw);
+    const int cin8 = (a.Cin + 7) >> 3;
+    const int ck8_full = a.CK >> 3;
+    const int CSh = (cin8 < ck8_full ? cin8 * 8 : a.CK) + kPadF16;  // halfs per patch pixel
+    const int plane = a.PH * a.PW * CSh;                              // halfs per plane
+    const int ntaps = S.nkh * S.nkw;
+    const int steps_full = (ntaps * ck8_full + 3) >> 2;
+    const int inv_kw = (65536 + S.nkw - 1) / S.nkw;
+    int pixoff[kMT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+      pixoff[m] = ((seg_r[m] + S.th0) * a.PW + (seg_q[m] * 16 + p) * a.sw + S.tw0) * CSh;
+
+    int chunk = 0;
+    for (int c8_0 = 0; c8_0 < cin8; c8_0 += ck8_full, ++chunk) {
+      const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
+      const int qn = ck8 * 2;  // float4 quads per pixel in this chunk
+      if (chunk) __syncthreads();
+      const int total = a.PH * a.PW * qn;
+      for (int idx = tid; idx < total; idx += kConvThreads) {
+        const int q = idx % qn;
+        const int pix = idx / qn;
+        const int pc = pix % a.PW;
+        const int pr = pix / a.PW;
+        const int h = h0 - a.pt + pr;
+        const int w = w0 * a.sw - a.pl + pc;
+        const int c = c8_0 * 8 + q * 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < a.H && w >= 0 && w < a.Win && c < a.Cin)
+          v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)h * a.Win + w) * a.Cin + c);
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = (_Float16)v[e];
+          lo[e] = (_Float16)(v[e] - (float)hi[e]);
+        }
+        _Float16* dst = sm + pix * CSh + q * 4;
+        *reinterpret_cast<f16x4*>(dst) = hi;
+        *reinterpret_cast<f16x4*>(dst + plane) = lo;
+      }
+      __syncthreads();
+
+      const int nk = ntaps * ck8;
+      const int nsteps = (nk + 3) >> 2;
+      const int inv_ck8 = (65536 + ck8 - 1) / ck8;
+      const _Float16* wbase = S.w16 + ((size_t)(chunk * steps_full) * S.nctp + ct0) * 1024 + lane * 8;
+      f16x8 wh[NT], wl[NT];
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn) {
+        wh[nn] = *reinterpret_cast<const f16x8*>(wbase + nn * 1024);
+        wl[nn] = *reinterpret_cast<const f16x8*>(wbase + nn * 1024 + 512);
+      }
+      for (int s = 0; s < nsteps; ++s) {
+        // prefetch the next step's weight fragments (clamped: the last prefetch is unused)
+        const int sn = (s + 1 < nsteps) ? s + 1 : s;
+        const _Float16* wnx = wbase + (size_t)sn * S.nctp * 1024;
+        f16x8 whn[NT], wln[NT];
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+          whn[nn] = *reinterpret_cast<const f16x8*>(wnx + nn * 1024);
+          wln[nn] = *reinterpret_cast<const f16x8*>(wnx + nn * 1024 + 512);
+        }
+        int kidx = 4 * s + g;
+        if (kidx >= nk) kidx = 0;  // padded K: its weights are zero, read any valid data
+        const int tap = (kidx * inv_ck8) >> 16;
+        const int c8 = kidx - tap * ck8;
+        const int ti = (tap * inv_kw) >> 16;
+        const int koff = (ti * a.PW + (tap - ti * S.nkw)) * CSh + c8 * 8;
+        f16x8 xh[kMT], xl[kMT];
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
-          const int pcol = (seg_q[m] * 16 + p) * a.sw + tw;
-          const int prow = seg_r[m] + th;
-          xv[m] = *reinterpret_cast<const f32x4*>(smem + (prow * a.PW + pcol) * CS + sub * 16 + g * 4);
+          xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
+          xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int m = 0; m < kMT; ++m)
 #pragma unroll
-          for (int m = 0; m < kMT; ++m)
+          for (int nn = 0; nn < NT; ++nn) {
+            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nn], xh[m], acc[m][nn], 0, 0, 0);
+            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xl[m], acc[m][nn], 0, 0, 0);
+            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xh[m], acc[m][nn], 0, 0, 0);
+          }
 #pragma unroll
-            for (int nn = 0; nn < NT; ++nn)
-              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nn][j], xv[m][j], acc[m][nn], 0, 0, 0);
+        for (int nn = 0; nn < NT; ++nn) {
+          wh[nn] = whn[nn];
+          wl[nn] = wln[nn];
+        }
       }
     }
   }
 
-  // ---- epilogue
+  // ---------------------------------------------------------------------------- epilogue
   f32x4 bv[NT];
 #pragma unroll
   for (int nn = 0; nn < NT; ++nn)
-    bv[nn] = *reinterpret_cast<const f32x4*>(a.bias + (ct0 + nn) * 16 + g * 4);
+    bv[nn] = *reinterpret_cast<const f32x4*>(S.bias + (ct0 + nn) * 16 + g * 4);
 
 #pragma unroll
   for (int m = 0; m < kMT; ++m) {
     const int oh = h0 + seg_r[m];
     const int j = w0 + seg_q[m] * 16 + p;
     const bool valid = (oh < a.H) && (j < a.Wconv);
-    const int ow = j * a.ow_mul + a.ow_off;
+    const int ow = j * a.ow_mul + S.ow_off;
     const size_t pix = ((size_t)n * a.H + oh) * a.Wout + ow;
 
     if constexpr (!HEAD) {
 #pragma unroll
       for (int nn = 0; nn < NT; ++nn) {
         const int co = (ct0 + nn) * 16 + g * 4;
-        if (valid && co < a.Cout) {
+        if (valid && co < S.Cout) {
           f32x4 v = acc[m][nn] + bv[nn];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], a.act);
+          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
           if (a.res1) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_C + a.co_off + co);
+            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_C + S.co_off + co);
             v = a.res1_mul ? v * r : v + r;
           }
-          if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_C + a.co_off + co);
-          *reinterpret_cast<f32x4*>(a.out + pix * a.out_C + a.co_off + co) = v;
+          if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_C + S.co_off + co);
+          *reinterpret_cast<f32x4*>(a.out + pix * a.out_C + S.co_off + co) = v;
         }
       }
     } else {
       // segmentation head (reference: nets/SegmentationNetwork.py:58-69).  The NT tiles hold
       // all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.
-      const int NC = a.Cout;
+      const int NC = S.Cout;
       float val[NT * 4];
       float best = -INFINITY;
       int bi = 0x7fffffff;
@@ -240,10 +363,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(const ConvArgs 
   }
 }
 
-// ---- MaxPool k x k, strides (1, sw), TF SAME (padding never wins)            (K6, K7)
+// ---- MaxPool kh x kw, strides (1, sw), TF SAME (padding never wins)            (K6, K7)
+// The 7x7 pool of CAM runs as two separable passes (1x7 then 7x1): max is associative, so the
+// result is bit-identical to the 49-tap window.
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in,
                                                       float* __restrict__ out, int N, int H, int Win,
-                                                      int Wout, int C, int k, int sw, int pt, int pl) {
+                                                      int Wout, int C, int kh, int kw, int sw, int pt,
+                                                      int pl) {
   const int c4n = C >> 2;
   const size_t total = (size_t)N * H * Wout * c4n;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -255,11 +381,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     const int h = (int)(pix % H);
     const int n = (int)(pix / H);
     f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < k; ++i) {
+    for (int i = 0; i < kh; ++i) {
       const int hh = h - pt + i;
       if (hh < 0 || hh >= H) continue;
       const float* row = in + ((size_t)n * H + hh) * Win * C + c4 * 4;
-      for (int j = 0; j < k; ++j) {
+      for (int j = 0; j < kw; ++j) {
         const int ww = wo * sw - pl + j;
         if (ww < 0 || ww >= Win) continue;
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + (size_t)ww * C);

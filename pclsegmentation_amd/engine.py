@@ -19,6 +19,9 @@ OK = 0
 ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_KEEP_ACTIVATIONS = 1
+FLAG_EXACT_F32 = 2
+MATH_F16X3, MATH_F32 = 0, 1
+MATH = {"f16x3": MATH_F16X3, "f32": MATH_F32}
 
 ARCH_IDS = {"squeezesegv2": 0, "darknet21": 1, "darknet53": 2}
 ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
@@ -85,11 +88,11 @@ def load_library():
   d5 = ctypes.POINTER(ctypes.c_double)
   lib.pclseg_op_normalize.argtypes = [vp, i32, i32, i32, d5, d5, vp, vp]
   lib.pclseg_op_conv2d.argtypes = [vp, i32, i32, i32, i32, f32p, i32, i32, i32, i32, f32p, f32p,
-                                   f32p, f32p, f32p, i32, vp, vp]
+                                   f32p, f32p, f32p, i32, vp, vp, i32]
   lib.pclseg_op_conv2d_transpose.argtypes = [vp, i32, i32, i32, i32, f32p, i32, f32p, f32p, f32p,
-                                             f32p, f32p, i32, vp]
+                                             f32p, f32p, i32, vp, i32]
   lib.pclseg_op_max_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp]
-  lib.pclseg_op_head.argtypes = [vp, vp, i32, i32, i32, i32, f32p, f32p, i32, i32, vp, vp, vp]
+  lib.pclseg_op_head.argtypes = [vp, vp, i32, i32, i32, i32, f32p, f32p, i32, i32, vp, vp, vp, i32]
   for name in EXPORTS:
     fn = getattr(lib, name)
     if name not in ("pclseg_last_error",):
@@ -250,7 +253,7 @@ def _opt(a):
   return None if a is None else _host_f32(a)
 
 
-def op_conv2d(x_dev, n, h, w, cin, kernel, stride_w, bias, bn, act, residual_dev, y_dev):
+def op_conv2d(x_dev, n, h, w, cin, kernel, stride_w, bias, bn, act, residual_dev, y_dev, math="f16x3"):
   lib = load_library()
   k = _host_f32(kernel)
   kh, kw, kcin, cout = k.shape
@@ -259,10 +262,10 @@ def op_conv2d(x_dev, n, h, w, cin, kernel, stride_w, bias, bn, act, residual_dev
   g, be, mu, var = [_opt(v) for v in (bn if bn is not None else (None,) * 4)]
   check(lib.pclseg_op_conv2d(_ptr(x_dev), n, h, w, cin, _ptr(k), kh, kw, cout, stride_w, _ptr(b),
                              _ptr(g), _ptr(be), _ptr(mu), _ptr(var), ACT[act], _ptr(residual_dev),
-                             _ptr(y_dev)))
+                             _ptr(y_dev), MATH[math]))
 
 
-def op_conv2d_transpose(x_dev, n, h, w, cin, kernel, bias, bn, act, y_dev):
+def op_conv2d_transpose(x_dev, n, h, w, cin, kernel, bias, bn, act, y_dev, math="f16x3"):
   lib = load_library()
   k = _host_f32(kernel)
   assert k.shape[:2] == (1, 4) and k.shape[3] == cin
@@ -270,7 +273,7 @@ def op_conv2d_transpose(x_dev, n, h, w, cin, kernel, bias, bn, act, y_dev):
   b = _opt(bias)
   g, be, mu, var = [_opt(v) for v in (bn if bn is not None else (None,) * 4)]
   check(lib.pclseg_op_conv2d_transpose(_ptr(x_dev), n, h, w, cin, _ptr(k), cout, _ptr(b), _ptr(g),
-                                       _ptr(be), _ptr(mu), _ptr(var), ACT[act], _ptr(y_dev)))
+                                       _ptr(be), _ptr(mu), _ptr(var), ACT[act], _ptr(y_dev), MATH[math]))
 
 
 def op_max_pool(x_dev, n, h, w, c, k, stride_w, y_dev):
@@ -278,10 +281,10 @@ def op_max_pool(x_dev, n, h, w, c, k, stride_w, y_dev):
 
 
 def op_head(x_dev, mask_dev, n, h, w, cin, kernel, bias, none_index, preds_dev, probs_dev=None,
-            logits_dev=None):
+            logits_dev=None, math="f16x3"):
   k = _host_f32(kernel)
   b = _host_f32(bias)
   nc = k.shape[3]
   check(load_library().pclseg_op_head(_ptr(x_dev), _ptr(mask_dev), n, h, w, cin, _ptr(k), _ptr(b),
                                       nc, none_index, _ptr(preds_dev), _ptr(probs_dev),
-                                      _ptr(logits_dev)))
+                                      _ptr(logits_dev), MATH[math]))

@@ -1,0 +1,70 @@
+"""The N > 1 path on CPU: two processes over gloo — contiguous scan sharding with no data-path
+collective, one weight broadcast, optional prediction gather."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pclsegmentation_amd import distributed as D
+from pclsegmentation_amd.nets.spec import squeezesegv2_spec
+from pclsegmentation_amd.nets.weights import synthetic_weights
+
+
+def test_shard_range_partitions():
+  for n in (0, 1, 5, 32, 255, 256):
+    for world in (1, 2, 3, 8):
+      spans = [D.shard_range(n, r, world) for r in range(world)]
+      assert spans[0][0] == 0 and spans[-1][1] == n
+      assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+      sizes = [hi - lo for lo, hi in spans]
+      assert max(sizes) - min(sizes) <= 1
+  assert [D.shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+
+
+def test_pack_unpack_round_trip():
+  spec = squeezesegv2_spec(11)
+  w = synthetic_weights(spec, 3)
+  flat = D.pack_weights(spec, w)
+  assert flat.dtype == np.float32 and flat.size == 931887
+  back = D.unpack_weights(spec, flat)
+  assert all(np.array_equal(w[k], back[k]) for k in w)
+
+
+def _worker(rank, world, port, q):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                    LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+  r, _, ws = D.init_process_group(backend="gloo")
+  assert (r, ws) == (rank, world)
+  spec = squeezesegv2_spec(11)
+  weights = synthetic_weights(spec, 4321) if rank == 0 else None
+  weights = D.broadcast_weights(spec, weights, src=0, device=torch.device("cpu"))
+  digest = float(sum(np.float64(v).sum() for v in weights.values()))
+  lo, hi = D.shard_range(5, rank, world)
+  local = torch.full((hi - lo, 2, 3), rank, dtype=torch.int32)      # "predictions" of my scans
+  local += torch.arange(lo, hi, dtype=torch.int32).view(-1, 1, 1) * 10
+  full = D.gather_predictions(local, 5, dst=0)
+  q.put((rank, digest, (lo, hi), None if full is None else full[:, 0, 0].tolist()))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_process_broadcast_and_sharding():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = sorted(q.get(timeout=120) for _ in range(2))
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0
+  want = float(sum(np.float64(v).sum() for v in synthetic_weights(squeezesegv2_spec(11), 4321).values()))
+  assert res[0][1] == want and res[1][1] == want          # rank 1 received rank 0's weights
+  assert res[0][2] == (0, 3) and res[1][2] == (3, 5)      # disjoint, covering
+  assert res[0][3] == [0, 10, 20, 31, 41] and res[1][3] is None

