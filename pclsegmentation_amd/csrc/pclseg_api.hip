@@ -153,14 +153,16 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 
 // ---- launch helpers -------------------------------------------------------------------------
 template <bool HEAD, bool F16>
-hipError_t launch_conv_nt(int nt, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
-  switch (nt) {
-    case 1: hipLaunchKernelGGL((conv_kernel<1, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((conv_kernel<2, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((conv_kernel<3, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((conv_kernel<4, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
+hipError_t launch_conv_cfg(int ntw, int wn, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+#define PCLSEG_LAUNCH(NTW_, WN_) \
+  hipLaunchKernelGGL((conv_kernel<NTW_, WN_, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a)
+  if (wn == 2 && ntw == 2 && !HEAD) { PCLSEG_LAUNCH(2, 2); }
+  else if (wn == 1 && ntw == 1) { PCLSEG_LAUNCH(1, 1); }
+  else if (wn == 1 && ntw == 2) { PCLSEG_LAUNCH(2, 1); }
+  else if (wn == 1 && ntw == 3) { PCLSEG_LAUNCH(3, 1); }
+  else if (wn == 1 && ntw == 4) { PCLSEG_LAUNCH(4, 1); }
+  else return hipErrorInvalidValue;
+#undef PCLSEG_LAUNCH
   return hipGetLastError();
 }
 
@@ -171,7 +173,7 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   a.Cin = op.cin_t;
   a.res1_mul = op.res1_mul ? 1 : 0;
   a.nsub = op.nsub;
-  a.CK = op.ck16;
+  a.CK = exact ? op.ck32 : op.ck16;
   int ny = 0;
   for (int i = 0; i < op.nsub; ++i) {
     const SubOp& su = op.sub[i];
@@ -181,46 +183,38 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
     d.bias = bias + su.b_off;
     d.Cout = su.cout;
     d.nctp = su.nctp;
-    d.ny = su.nctp / op.nt;
+    d.ny = su.nctp / (op.ntw * op.wn);
     d.co_off = su.co_off;
     d.th0 = su.th0; d.tw0 = su.tw0; d.nkh = su.nkh; d.nkw = su.nkw;
     d.ow_off = su.ow_off;
     d.act = su.act;
     ny += d.ny;
   }
-  const bool flat = (op.kind == OP_CONV && op.pkh == 1 && op.pkw == 1 && op.sw == 1);
   int wo, pl, ho, pt;
   same_pad(Win, op.pkw, op.sw, &wo, &pl);
   same_pad(H, op.pkh, 1, &ho, &pt);
   a.sw = op.sw; a.pt = pt; a.pl = op.pl_fixed >= 0 ? op.pl_fixed : pl;
   a.ow_mul = op.ow_mul;
-  if (flat) {
+  if (op_is_flat(op)) {
     a.N = 1; a.H = 1; a.Win = N * H * Win; a.Wconv = a.Wout = a.Win;
-    a.TH = 1; a.SEGW = kSegsPerBlock;
   } else {
     a.N = N; a.H = H; a.Win = Win;
     a.Wconv = op.ow_mul == 2 ? Win : wo;
     a.Wout = op.ow_mul == 2 ? 2 * Win : wo;
-    a.TH = kSegsPerBlock; a.SEGW = 1;
   }
-  a.PH = a.TH + op.pkh - 1;
-  a.PW = (a.SEGW * 16 - 1) * a.sw + op.pkw;
+  const TileGeom t = tile_geom(op);
+  a.TH = t.TH; a.SEGW = t.SEGW; a.PH = t.PH; a.PW = t.PW;
+  a.inv_pw = ((1 << 20) + a.PW - 1) / a.PW;
   a.tilesH = (a.H + a.TH - 1) / a.TH;
   a.tilesW = (a.Wconv + a.SEGW * 16 - 1) / (a.SEGW * 16);
-  size_t lds;
-  if (exact) {
-    const int cinp = ((op.cin_t + 15) / 16) * 16;
-    lds = (size_t)a.PH * a.PW * (std::min(cinp, kChunk32) + kPadF32) * sizeof(float);
-  } else {
-    const int cin8 = (op.cin_t + 7) / 8;
-    lds = (size_t)2 * a.PH * a.PW * (std::min(cin8 * 8, op.ck16) + kPadF16) * sizeof(_Float16);
-  }
+  const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)ny);
   if (op.kind == OP_HEAD)
-    return exact ? launch_conv_nt<true, false>(op.nt, grid, lds, s, a)
-                 : launch_conv_nt<true, true>(op.nt, grid, lds, s, a);
-  return exact ? launch_conv_nt<false, false>(op.nt, grid, lds, s, a)
-               : launch_conv_nt<false, true>(op.nt, grid, lds, s, a);
+    return exact ? launch_conv_cfg<true, false>(op.ntw, op.wn, grid, lds, s, a)
+                 : launch_conv_cfg<true, true>(op.ntw, op.wn, grid, lds, s, a);
+  return exact ? launch_conv_cfg<false, false>(op.ntw, op.wn, grid, lds, s, a)
+               : launch_conv_cfg<false, true>(op.ntw, op.wn, grid, lds, s, a);
 }
 
 hipError_t launch_pool(const float* in, float* out, int N, int H, int Win, int C, int kh, int kw,

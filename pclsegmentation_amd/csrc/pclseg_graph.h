@@ -69,8 +69,9 @@ struct Op {
   int ow_mul = 1;        // output column = j*ow_mul + sub.ow_off (2 for transposed conv)
   int nsub = 1;
   SubOp sub[2];
-  int nt = 1;            // 16-cout tiles per block (template parameter of the kernel)
-  int ck16 = 64;         // channels per LDS pass in split-f16 mode
+  int ntw = 1, wn = 1;   // kernel template: 16-cout tiles per wave, wave columns per block
+  int ck16 = 64;         // channels per LDS pass, split-f16 mode
+  int ck32 = 32;         // channels per LDS pass, exact-f32 mode
   int pool_kh = 1, pool_kw = 1;
   std::string name() const { return sub[0].name; }
 };
@@ -95,31 +96,64 @@ inline void same_pad(int size, int k, int s, int* out, int* before) {
   *before = total / 2;
 }
 
-inline int choose_nt(int nct) {
-  if (nct % 4 == 0) return 4;
-  if (nct % 3 == 0) return 3;
-  if (nct % 2 == 0) return 2;
-  if (nct == 1) return 1;
-  return 4;
+// ---- block / LDS geometry shared by the planner and the launcher
+struct TileGeom { int TH, SEGW, PH, PW; };
+
+inline bool op_is_flat(const Op& op) {
+  return op.kind == OP_CONV && op.pkh == 1 && op.pkw == 1 && op.sw == 1 && op.ow_mul == 1;
 }
 
-// Geometry of the packed parameters of one op (shared by the graph and the stand-alone ops).
-// LDS budget decides the split-f16 chunk: two planes of PH*PW*(CK+8) halfs must fit 64 KiB.
+// A block covers 16/wn segments of 16 pixels: 1x1 convs walk the flattened N*H*W pixel row,
+// everything else takes an 8-row tile, 16 or 32 columns wide.
+inline TileGeom tile_geom(const Op& op) {
+  TileGeom t;
+  const int S = 16 / op.wn;
+  if (op_is_flat(op)) { t.TH = 1; t.SEGW = S; }
+  else { t.TH = 8; t.SEGW = S / 8; }
+  t.PH = t.TH + op.pkh - 1;
+  t.PW = (t.SEGW * 16 - 1) * op.sw + op.pkw;
+  return t;
+}
+
+// halfs per staged pixel in split-f16 mode: the chunk's float4 quads rounded up to a power of
+// two (the staging loop indexes with shifts), plus padding
+inline int f16_csh(int cin_t, int ck) {
+  const int cin8 = (cin_t + 7) / 8;
+  const int qmax = std::min(cin8, ck / 8) * 2;
+  int qs = 2;
+  while (qs < qmax) qs *= 2;
+  return qs * 4 + 8;
+}
+inline int64_t lds_bytes_f16(const Op& op, int ck) {
+  const TileGeom t = tile_geom(op);
+  return (int64_t)2 * t.PH * t.PW * f16_csh(op.cin_t, ck) * 2;
+}
+inline int64_t lds_bytes_f32(const Op& op, int ck) {
+  const TileGeom t = tile_geom(op);
+  const int cinp = ((op.cin_t + 15) / 16) * 16;
+  return (int64_t)t.PH * t.PW * (std::min(cinp, ck) + 4) * 4;
+}
+
+// Kernel configuration + packed-parameter geometry of one op (graph ops and stand-alone ops).
 inline void op_geometry(Op* op) {
   if (op->kind == OP_POOL) return;
   const int nct = (op->sub[0].cout + 15) / 16;
-  op->nt = (op->kind == OP_HEAD) ? nct : choose_nt(nct);
+  if (op->kind == OP_HEAD) { op->wn = 1; op->ntw = nct; }
+  else if (nct % 4 == 0) { op->ntw = 2; op->wn = 2; }
+  else if (nct % 3 == 0) { op->ntw = 3; op->wn = 1; }
+  else if (nct % 2 == 0) { op->ntw = 2; op->wn = 1; }
+  else if (nct == 1) { op->ntw = 1; op->wn = 1; }
+  else { op->ntw = 2; op->wn = 2; }
+  const int group = op->ntw * op->wn;
   for (int i = 0; i < op->nsub; ++i) {
     const int n = (op->sub[i].cout + 15) / 16;
-    op->sub[i].nctp = ((n + op->nt - 1) / op->nt) * op->nt;
+    op->sub[i].nctp = ((n + group - 1) / group) * group;
   }
-  const bool flat = (op->kind == OP_CONV && op->pkh == 1 && op->pkw == 1 && op->sw == 1);
-  const int TH = flat ? 1 : 8, SEGW = flat ? 8 : 1;
-  const int PH = TH + op->pkh - 1, PW = (SEGW * 16 - 1) * op->sw + op->pkw;
-  const int cin8 = (op->cin_t + 7) / 8;
+  const int64_t budget = 64 * 1024;  // default dynamic-LDS limit per block
   op->ck16 = 64;
-  auto lds = [&](int ck) { return (int64_t)2 * PH * PW * (std::min(cin8 * 8, ck) + 8) * 2; };
-  if (lds(64) > 64 * 1024) op->ck16 = 32;
+  while (op->ck16 > 16 && lds_bytes_f16(*op, op->ck16) > budget) op->ck16 /= 2;
+  op->ck32 = 32;
+  while (op->ck32 > 16 && lds_bytes_f32(*op, op->ck32) > budget) op->ck32 /= 2;
 }
 
 inline int64_t sub_w32_floats(const Op& op, const SubOp& s) {

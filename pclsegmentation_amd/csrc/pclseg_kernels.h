@@ -36,11 +36,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
 
 constexpr int kConvThreads = 256;  // 4 waves, one per SIMD
-constexpr int kMT = 2;             // 16-pixel segments per wave
-constexpr int kSegsPerBlock = 4 * kMT;
-constexpr int kChunk32 = 32;       // input channels staged per LDS pass, exact-f32 mode
+constexpr int kMTW = 4;            // 16-pixel segments per wave
 constexpr int kPadF32 = 4;         // floats of per-pixel LDS padding (bank spread)
 constexpr int kPadF16 = 8;         // halfs of per-pixel LDS padding
+constexpr int kStageBatch = 8;     // global loads a thread keeps in flight while staging
 
 // A sub-convolution: a window of taps inside the staged patch, with its own weights / bias /
 // activation / destination channel slice / output column phase.
@@ -48,7 +47,7 @@ struct ConvSub {
   const float* w32;     // exact mode: [tap][c16][ct][lane][4] floats
   const _Float16* w16;  // f16x3 mode: [chunk-step][ct][hi|lo][lane][8] halfs
   const float* bias;    // [nctp*16]
-  int Cout, nctp, ny;   // ny = nctp / NT blocks along grid.y
+  int Cout, nctp, ny;   // ny = blocks along grid.y = nctp / (NTW*WN)
   int co_off;           // destination channel offset
   int th0, tw0, nkh, nkw;  // tap window inside the patch
   int ow_off;           // output column = j*ow_mul + ow_off
@@ -69,7 +68,8 @@ struct ConvArgs {
   int sw, pt, pl, ow_mul;
   int TH, SEGW, PH, PW, tilesH, tilesW;
   int res1_mul, none_index;
-  int CK;  // f16x3 mode: channels staged per LDS pass (32 or 64)
+  int CK;      // channels staged per LDS pass (f16x3: 64/32/16, exact: 32/16)
+  int inv_pw;  // ceil(2^20 / PW): pixel index -> patch row by multiply-shift
   int nsub;
   ConvSub sub[2];
 };
@@ -83,12 +83,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int NT, bool HEAD, bool F16X3>
+// Block = 4 waves arranged WM x WN (WM = 4/WN): wave (wm, wn) owns kMTW pixel segments
+// {wm*4 .. wm*4+3} and NTW 16-cout tiles {wn*NTW ..}.  WN = 2 halves the weight fragments each
+// wave streams from L2 (the block shares one 64-cout group), WN = 1 keeps all couts of a pixel in
+// one wave (needed by the head's argmax) on a 256-pixel block.
+template <int NTW, int WN, bool HEAD, bool F16X3>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % WN, wm = wave / WN;
   const int p = lane & 15;  // pixel within the 16-pixel segment
   const int g = lane >> 4;  // k-group (operands) / cout quad (accumulator)
 
@@ -102,21 +107,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
   const int by = blockIdx.y;
   const int si = (a.nsub > 1 && by >= a.sub[0].ny) ? 1 : 0;
   const ConvSub& S = a.sub[si];
-  const int ct0 = (by - (si ? a.sub[0].ny : 0)) * NT;
+  const int ct0 = (by - (si ? a.sub[0].ny : 0)) * (NTW * WN) + wn * NTW;
 
-  f32x4 acc[kMT][NT];
+  f32x4 acc[kMTW][NTW];
 #pragma unroll
-  for (int m = 0; m < kMT; ++m)
+  for (int m = 0; m < kMTW; ++m)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float* in_n = a.in + (size_t)n * a.H * a.Win * a.Cin;
+  const int npix = a.PH * a.PW;
 
-  // this wave's two segments: (row, column-segment) inside the tile
-  int seg_r[kMT], seg_q[kMT];
+  // this wave's segments: (row, column-segment) inside the tile
+  int seg_r[kMTW], seg_q[kMTW];
 #pragma unroll
-  for (int m = 0; m < kMT; ++m) {
-    const int seg = wave * kMT + m;
+  for (int m = 0; m < kMTW; ++m) {
+    const int seg = wm * kMTW + m;
     seg_r[m] = seg / a.SEGW;
     seg_q[m] = seg - seg_r[m] * a.SEGW;
   }
@@ -126,25 +132,38 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
     float* smem = reinterpret_cast<float*>(smem_raw);
     const int nc16 = (a.Cin + 15) >> 4;
     const int cinp = nc16 * 16;
-    const int CS = (cinp < kChunk32 ? cinp : kChunk32) + kPadF32;  // floats per patch pixel
+    const int CS = (cinp < a.CK ? cinp : a.CK) + kPadF32;  // floats per patch pixel
     const int ntaps = S.nkh * S.nkw;
-    for (int c0 = 0; c0 < cinp; c0 += kChunk32) {
-      const int ckp = (cinp - c0) < kChunk32 ? (cinp - c0) : kChunk32;
+    for (int c0 = 0; c0 < cinp; c0 += a.CK) {
+      const int ckp = (cinp - c0) < a.CK ? (cinp - c0) : a.CK;
       const int cqn = ckp >> 2;
       if (c0) __syncthreads();
-      const int total = a.PH * a.PW * cqn;
-      for (int idx = tid; idx < total; idx += kConvThreads) {
-        const int cq = idx % cqn;
-        const int pix = idx / cqn;
-        const int pc = pix % a.PW;
-        const int pr = pix / a.PW;
-        const int h = h0 - a.pt + pr;
-        const int w = w0 * a.sw - a.pl + pc;
-        const int c = c0 + cq * 4;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (h >= 0 && h < a.H && w >= 0 && w < a.Win && c < a.Cin)
-          v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)h * a.Win + w) * a.Cin + c);
-        *reinterpret_cast<f32x4*>(smem + (pr * a.PW + pc) * CS + cq * 4) = v;
+      // cqn is 4 or 8: thread -> (fixed channel quad, strided pixels); loads are issued in
+      // batches of kStageBatch so their latencies overlap
+      const int lq = cqn == 8 ? 3 : 2;
+      const int sq = tid & (cqn - 1);
+      const int spstep = kConvThreads >> lq;
+      const int c = c0 + sq * 4;
+      const bool cok = c < a.Cin;
+      for (int pb = tid >> lq; pb < npix; pb += kStageBatch * spstep) {
+        f32x4 v[kStageBatch];
+#pragma unroll
+        for (int k = 0; k < kStageBatch; ++k) {
+          const int pix = pb + k * spstep;
+          const int pr = (int)(((unsigned)pix * (unsigned)a.inv_pw) >> 20);
+          const int pc = pix - pr * a.PW;
+          const int h = h0 - a.pt + pr;
+          const int w = w0 * a.sw - a.pl + pc;
+          const bool ok = cok && pix < npix && h >= 0 && h < a.H && w >= 0 && w < a.Win;
+          const float* src = ok ? in_n + ((size_t)h * a.Win + w) * a.Cin + c : in_n;
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+          v[k] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < kStageBatch; ++k) {
+          const int pix = pb + k * spstep;
+          if (pix < npix) *reinterpret_cast<f32x4*>(smem + pix * CS + sq * 4) = v[k];
+        }
       }
       __syncthreads();
       const int nsubk = ckp >> 4;
@@ -155,12 +174,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
         for (int sk = 0; sk < nsubk; ++sk) {
           const int c16 = (c0 >> 4) + sk;
           const float* wb = S.w32 + ((size_t)(t * nc16 + c16) * S.nctp + ct0) * 256 + lane * 4;
-          f32x4 wv[NT];
+          f32x4 wv[NTW];
 #pragma unroll
-          for (int nn = 0; nn < NT; ++nn) wv[nn] = *reinterpret_cast<const f32x4*>(wb + nn * 256);
-          f32x4 xv[kMT];
+          for (int nn = 0; nn < NTW; ++nn) wv[nn] = *reinterpret_cast<const f32x4*>(wb + nn * 256);
+          f32x4 xv[kMTW];
 #pragma unroll
-          for (int m = 0; m < kMT; ++m) {
+          for (int m = 0; m < kMTW; ++m) {
             const int pcol = (seg_q[m] * 16 + p) * a.sw + tw;
             const int prow = seg_r[m] + th;
             xv[m] = *reinterpret_cast<const f32x4*>(smem + (prow * a.PW + pcol) * CS + sk * 16 + g * 4);
@@ -168,117 +187,148 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int m = 0; m < kMT; ++m)
+            for (int m = 0; m < kMTW; ++m)
 #pragma unroll
-              for (int nn = 0; nn < NT; ++nn)
+              for (int nn = 0; nn < NTW; ++nn)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nn][j], xv[m][j], acc[m][nn], 0, 0, 0);
         }
       }
     }
   } else {
     // ------------------------------------------------------------ split-f16 matrix cores
-    // LDS: two planes (hi, lo) of [PH][PW][CSh] halfs.  K runs over (tap, 8-channel group)
+    // LDS: two planes (hi, lo) of [PH*PW][CSh] halfs.  K runs over (tap, 8-channel group)
     // pairs: lane group g of K-step s owns pair kidx = 4s + g, so taps with few channels
     // (Cin = 16, 48) still fill the 32-deep MFMA.
     _Float16* sm = reinterpret_cast<_Float16*>(smem_raw);
     const int cin8 = (a.Cin + 7) >> 3;
     const int ck8_full = a.CK >> 3;
-    const int CSh = (cin8 < ck8_full ? cin8 * 8 : a.CK) + kPadF16;  // halfs per patch pixel
-    const int plane = a.PH * a.PW * CSh;                              // halfs per plane
+    // staged float4 quads per pixel: next power of two of the widest chunk (zero-filled), so the
+    // staging index math is shifts only
+    const int qmax = (cin8 < ck8_full ? cin8 : ck8_full) * 2;
+    int lq = 1;
+    while ((1 << lq) < qmax) ++lq;
+    const int qs = 1 << lq;
+    const int CSh = qs * 4 + kPadF16;  // halfs per patch pixel
+    const int plane = npix * CSh;      // halfs per plane
     const int ntaps = S.nkh * S.nkw;
     const int steps_full = (ntaps * ck8_full + 3) >> 2;
     const int inv_kw = (65536 + S.nkw - 1) / S.nkw;
-    int pixoff[kMT];
+    int pixoff[kMTW];
 #pragma unroll
-    for (int m = 0; m < kMT; ++m)
+    for (int m = 0; m < kMTW; ++m)
       pixoff[m] = ((seg_r[m] + S.th0) * a.PW + (seg_q[m] * 16 + p) * a.sw + S.tw0) * CSh;
+
+    const int sq = tid & (qs - 1);        // this thread's channel quad (fixed: 256 % qs == 0)
+    const int spix0 = tid >> lq;
+    const int spstep = kConvThreads >> lq;
+    const int hbase = h0 - a.pt, wbase = w0 * a.sw - a.pl;
 
     int chunk = 0;
     for (int c8_0 = 0; c8_0 < cin8; c8_0 += ck8_full, ++chunk) {
       const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
-      const int qn = ck8 * 2;  // float4 quads per pixel in this chunk
       if (chunk) __syncthreads();
-      const int total = a.PH * a.PW * qn;
-      for (int idx = tid; idx < total; idx += kConvThreads) {
-        const int q = idx % qn;
-        const int pix = idx / qn;
-        const int pc = pix % a.PW;
-        const int pr = pix / a.PW;
-        const int h = h0 - a.pt + pr;
-        const int w = w0 * a.sw - a.pl + pc;
-        const int c = c8_0 * 8 + q * 4;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (h >= 0 && h < a.H && w >= 0 && w < a.Win && c < a.Cin)
-          v = *reinterpret_cast<const f32x4*>(in_n + ((size_t)h * a.Win + w) * a.Cin + c);
-        f16x4 hi, lo;
+      {
+        const int c = c8_0 * 8 + sq * 4;
+        const bool cok = (c < a.Cin) && (sq < ck8 * 2);
+        for (int pb = spix0; pb < npix; pb += kStageBatch * spstep) {
+          f32x4 v[kStageBatch];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          hi[e] = (_Float16)v[e];
-          lo[e] = (_Float16)(v[e] - (float)hi[e]);
+          for (int k = 0; k < kStageBatch; ++k) {
+            const int pix = pb + k * spstep;
+            const int pr = (int)(((unsigned)pix * (unsigned)a.inv_pw) >> 20);
+            const int pc = pix - pr * a.PW;
+            const int h = hbase + pr;
+            const int w = wbase + pc;
+            const bool ok = cok && pix < npix && h >= 0 && h < a.H && w >= 0 && w < a.Win;
+            const float* src = ok ? in_n + ((size_t)h * a.Win + w) * a.Cin + c : in_n;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+            v[k] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int k = 0; k < kStageBatch; ++k) {
+            const int pix = pb + k * spstep;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              hi[e] = (_Float16)v[k][e];
+              lo[e] = (_Float16)(v[k][e] - (float)hi[e]);
+            }
+            if (pix < npix) {
+              _Float16* dst = sm + pix * CSh + sq * 4;
+              *reinterpret_cast<f16x4*>(dst) = hi;
+              *reinterpret_cast<f16x4*>(dst + plane) = lo;
+            }
+          }
         }
-        _Float16* dst = sm + pix * CSh + q * 4;
-        *reinterpret_cast<f16x4*>(dst) = hi;
-        *reinterpret_cast<f16x4*>(dst + plane) = lo;
       }
       __syncthreads();
 
       const int nk = ntaps * ck8;
       const int nsteps = (nk + 3) >> 2;
       const int inv_ck8 = (65536 + ck8 - 1) / ck8;
-      const _Float16* wbase = S.w16 + ((size_t)(chunk * steps_full) * S.nctp + ct0) * 1024 + lane * 8;
-      f16x8 wh[NT], wl[NT];
+      const _Float16* wbase16 = S.w16 + ((size_t)(chunk * steps_full) * S.nctp + ct0) * 1024 + lane * 8;
+      // Weight fragments stream from L2 through a D-deep register ring: the loads of step s+D
+      // are issued as soon as step s has consumed its slot, so ~D steps of MFMA work cover the
+      // L2 latency (one step ahead is far too little: a step is only 12*NTW MFMAs).
+      constexpr int D = NTW <= 2 ? 4 : 2;
+      f16x8 wh[D][NTW], wl[D][NTW];
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) {
-        wh[nn] = *reinterpret_cast<const f16x8*>(wbase + nn * 1024);
-        wl[nn] = *reinterpret_cast<const f16x8*>(wbase + nn * 1024 + 512);
+      for (int d = 0; d < D; ++d) {
+        const int sd = d < nsteps ? d : nsteps - 1;
+        const _Float16* wp = wbase16 + (size_t)sd * S.nctp * 1024;
+#pragma unroll
+        for (int nn = 0; nn < NTW; ++nn) {
+          wh[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+          wl[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+        }
       }
-      for (int s = 0; s < nsteps; ++s) {
-        // prefetch the next step's weight fragments (clamped: the last prefetch is unused)
-        const int sn = (s + 1 < nsteps) ? s + 1 : s;
-        const _Float16* wnx = wbase + (size_t)sn * S.nctp * 1024;
-        f16x8 whn[NT], wln[NT];
+      for (int s0 = 0; s0 < nsteps; s0 += D) {
 #pragma unroll
-        for (int nn = 0; nn < NT; ++nn) {
-          whn[nn] = *reinterpret_cast<const f16x8*>(wnx + nn * 1024);
-          wln[nn] = *reinterpret_cast<const f16x8*>(wnx + nn * 1024 + 512);
-        }
-        int kidx = 4 * s + g;
-        if (kidx >= nk) kidx = 0;  // padded K: its weights are zero, read any valid data
-        const int tap = (kidx * inv_ck8) >> 16;
-        const int c8 = kidx - tap * ck8;
-        const int ti = (tap * inv_kw) >> 16;
-        const int koff = (ti * a.PW + (tap - ti * S.nkw)) * CSh + c8 * 8;
-        f16x8 xh[kMT], xl[kMT];
+        for (int d = 0; d < D; ++d) {
+          const int s = s0 + d;
+          if (s < nsteps) {
+            int kidx = 4 * s + g;
+            if (kidx >= nk) kidx = 0;  // padded K: its weights are zero, read any valid data
+            const int tap = (kidx * inv_ck8) >> 16;
+            const int c8 = kidx - tap * ck8;
+            const int ti = (tap * inv_kw) >> 16;
+            const int koff = (ti * a.PW + (tap - ti * S.nkw)) * CSh + c8 * 8;
+            f16x8 xh[kMTW], xl[kMTW];
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-          xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
-          xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
-        }
+            for (int m = 0; m < kMTW; ++m) {
+              xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
+              xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
+            }
 #pragma unroll
-        for (int m = 0; m < kMT; ++m)
+            for (int m = 0; m < kMTW; ++m)
 #pragma unroll
-          for (int nn = 0; nn < NT; ++nn) {
-            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nn], xh[m], acc[m][nn], 0, 0, 0);
-            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xl[m], acc[m][nn], 0, 0, 0);
-            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xh[m], acc[m][nn], 0, 0, 0);
+              for (int nn = 0; nn < NTW; ++nn) {
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][nn], xh[m], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][nn], xl[m], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][nn], xh[m], acc[m][nn], 0, 0, 0);
+              }
+            // refill this slot with step s + D (clamped: trailing refills are unused)
+            const int sn = (s + D < nsteps) ? s + D : nsteps - 1;
+            const _Float16* wp = wbase16 + (size_t)sn * S.nctp * 1024;
+#pragma unroll
+            for (int nn = 0; nn < NTW; ++nn) {
+              wh[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+              wl[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+            }
           }
-#pragma unroll
-        for (int nn = 0; nn < NT; ++nn) {
-          wh[nn] = whn[nn];
-          wl[nn] = wln[nn];
         }
       }
     }
   }
 
   // ---------------------------------------------------------------------------- epilogue
-  f32x4 bv[NT];
+  f32x4 bv[NTW];
 #pragma unroll
-  for (int nn = 0; nn < NT; ++nn)
+  for (int nn = 0; nn < NTW; ++nn)
     bv[nn] = *reinterpret_cast<const f32x4*>(S.bias + (ct0 + nn) * 16 + g * 4);
 
 #pragma unroll
-  for (int m = 0; m < kMT; ++m) {
+  for (int m = 0; m < kMTW; ++m) {
     const int oh = h0 + seg_r[m];
     const int j = w0 + seg_q[m] * 16 + p;
     const bool valid = (oh < a.H) && (j < a.Wconv);
@@ -287,7 +337,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
 
     if constexpr (!HEAD) {
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn) {
+      for (int nn = 0; nn < NTW; ++nn) {
         const int co = (ct0 + nn) * 16 + g * 4;
         if (valid && co < S.Cout) {
           f32x4 v = acc[m][nn] + bv[nn];
@@ -305,11 +355,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
       // segmentation head (reference: nets/SegmentationNetwork.py:58-69).  The NT tiles hold
       // all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.
       const int NC = S.Cout;
-      float val[NT * 4];
+      float val[NTW * 4];
       float best = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn)
+      for (int nn = 0; nn < NTW; ++nn)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int co = nn * 16 + g * 4 + i;
@@ -331,7 +381,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
         // probabilities exactly as the reference does (lowest index wins ties).
         float s = 0.f;
 #pragma unroll
-        for (int nn = 0; nn < NT; ++nn)
+        for (int nn = 0; nn < NTW; ++nn)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (nn * 16 + g * 4 + i < NC) s += expf(val[nn * 4 + i] - best);
@@ -340,7 +390,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
         float pbest = -1.f;
         int pbi = 0x7fffffff;
 #pragma unroll
-        for (int nn = 0; nn < NT; ++nn)
+        for (int nn = 0; nn < NTW; ++nn)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int co = nn * 16 + g * 4 + i;
