@@ -217,6 +217,18 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
                : launch_conv_cfg<false, true>(op.ntw, op.wn, grid, lds, s, a);
 }
 
+hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {
+  c.N = N; c.H = H; c.W = W;
+  c.tilesH = (H + kCamTH - 1) / kCamTH;
+  c.tilesW = (W + kCamTW - 1) / kCamTW;
+  const dim3 grid((unsigned)(N * c.tilesH * c.tilesW));
+  const size_t lds = (size_t)(kCamPatchFloats + kCamTmpFloats + kCamCK * (C / 16)) * sizeof(float);
+  if (C == 64) hipLaunchKernelGGL((cam_kernel<64, 4>), grid, dim3(256), lds, s, c);
+  else if (C == 128) hipLaunchKernelGGL((cam_kernel<128, 8>), grid, dim3(256), lds, s, c);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_pool(const float* in, float* out, int N, int H, int Win, int C, int kh, int kw,
                        int sw, hipStream_t s) {
   int wo, pl, ho, pt;
@@ -253,6 +265,16 @@ int run_ops(pclseg_handle* h, int cnt, const uint8_t* mask, int32_t* preds, floa
       HIP_TRY(h, launch_pool(in, out, cnt, ti.H, ti.W, ti.C, op.pool_kh, op.pool_kw, op.sw, h->stream));
       continue;
     }
+    if (op.kind == OP_CAM) {
+      CamArgs c;
+      c.x = in;
+      c.out = h->d_arena + g.tensors[op.out].offset;
+      const int C = op.cin_t, R = C / 16;
+      c.w1 = h->d_bias + op.sub[0].b_off; c.b1 = c.w1 + (size_t)C * R;
+      c.w2 = h->d_bias + op.sub[1].b_off; c.b2 = c.w2 + (size_t)R * C;
+      HIP_TRY(h, launch_cam(c, cnt, ti.H, ti.W, C, h->stream));
+      continue;
+    }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in;
@@ -268,6 +290,7 @@ int run_ops(pclseg_handle* h, int cnt, const uint8_t* mask, int32_t* preds, floa
       a.out_C = to.C;
       if (op.res1 >= 0) { a.res1 = h->d_arena + g.tensors[op.res1].offset; a.res1_C = g.tensors[op.res1].C; }
       if (op.res2 >= 0) { a.res2 = h->d_arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
+      if (op.sk_in >= 0) { a.skx = h->d_arena + g.tensors[op.sk_in].offset; a.skw = h->d_bias + op.sk.b_off; }
     }
     HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, h->exact, h->stream));
   }
@@ -527,9 +550,43 @@ int pclseg_finalize(pclseg_handle* h) {
   std::vector<float> bias((size_t)h->g.packed_bias_floats, 0.0f);
   for (const Op& op : h->g.ops) {
     if (op.kind == OP_POOL) continue;
+    if (op.sk_in >= 0) {  // fused skip branch: [8][C] folded 1x1 weights (rows >= Cin zero) + [C] bias
+      const SubOp& su = op.sk;
+      FoldIn f;
+      f.kernel = W(su.name + "/kernel"); f.bias = W(su.name + "/bias");
+      f.gamma = W(su.bn + "/gamma"); f.beta = W(su.bn + "/beta");
+      f.mean = W(su.bn + "/moving_mean"); f.var = W(su.bn + "/moving_variance");
+      if (!f.kernel || !f.bias || !f.gamma || !f.beta || !f.mean || !f.var)
+        return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", su.name.c_str()));
+      std::vector<double> scale, shift;
+      fold_bn(su, f, &scale, &shift);
+      const int cin = (int)h->g.weights[h->g.weight_index[su.name + "/kernel"]].shape[2];
+      float* dst = bias.data() + su.b_off;
+      for (int ci = 0; ci < 8; ++ci)
+        for (int co = 0; co < su.cout; ++co)
+          dst[(size_t)ci * su.cout + co] =
+              ci < cin ? (float)((double)f.kernel[(size_t)ci * su.cout + co] * scale[co]) : 0.0f;
+      for (int co = 0; co < su.cout; ++co) dst[(size_t)8 * su.cout + co] = (float)shift[co];
+    }
     for (int i = 0; i < op.nsub; ++i) {
       const SubOp& su = op.sub[i];
       FoldIn f;
+      if (op.kind == OP_CAM) {  // plain row-major [Cin][Cout] * scale, then shift
+        f.kernel = W(su.name + "/kernel"); f.bias = W(su.name + "/bias");
+        f.gamma = W(su.bn + "/gamma"); f.beta = W(su.bn + "/beta");
+        f.mean = W(su.bn + "/moving_mean"); f.var = W(su.bn + "/moving_variance");
+        if (!f.kernel || !f.bias || !f.gamma || !f.beta || !f.mean || !f.var)
+          return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", su.name.c_str()));
+        std::vector<double> scale, shift;
+        fold_bn(su, f, &scale, &shift);
+        const int cin = i == 0 ? op.cin_t : op.cin_t / 16;
+        float* dst = bias.data() + su.b_off;
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < su.cout; ++co)
+            dst[(size_t)ci * su.cout + co] = (float)((double)f.kernel[(size_t)ci * su.cout + co] * scale[co]);
+        for (int co = 0; co < su.cout; ++co) dst[(size_t)cin * su.cout + co] = (float)shift[co];
+        continue;
+      }
       f.kernel = W(su.name + "/kernel");
       f.bias = su.has_bias ? W(su.name + "/bias") : nullptr;
       if (!su.bn.empty()) {

@@ -20,7 +20,7 @@
 
 namespace pclseg {
 
-enum OpKind { OP_CONV = 0, OP_POOL = 2, OP_HEAD = 3 };
+enum OpKind { OP_CONV = 0, OP_POOL = 2, OP_HEAD = 3, OP_CAM = 4 };
 
 struct WeightInfo {
   std::string name;
@@ -73,6 +73,10 @@ struct Op {
   int ck16 = 64;         // channels per LDS pass, split-f16 mode
   int ck32 = 32;         // channels per LDS pass, exact-f32 mode
   int pool_kh = 1, pool_kw = 1;
+  // optional fused skip branch (SqueezeSegV2 conv1_skip/bn1_skip): BN(conv1x1(sk_in)) is added
+  // in the epilogue; `sk` names its Keras tensors, sk.b_off locates [8][C] weights + [C] bias
+  int sk_in = -1;
+  SubOp sk;
   std::string name() const { return sub[0].name; }
 };
 
@@ -136,7 +140,7 @@ inline int64_t lds_bytes_f32(const Op& op, int ck) {
 
 // Kernel configuration + packed-parameter geometry of one op (graph ops and stand-alone ops).
 inline void op_geometry(Op* op) {
-  if (op->kind == OP_POOL) return;
+  if (op->kind == OP_POOL || op->kind == OP_CAM) return;
   const int nct = (op->sub[0].cout + 15) / 16;
   if (op->kind == OP_HEAD) { op->wn = 1; op->ntw = nct; }
   else if (nct % 4 == 0) { op->ntw = 2; op->wn = 2; }
@@ -249,7 +253,7 @@ class GraphBuilder {
 
   // FIRE / FIREUP expand stage: relu(bn(1x1)) || relu(bn(3x3)) over the same input, written to
   // the two channel slices of `out` (tf.concat), one launch, one staged patch.
-  void expand_pair(const std::string& p, int in, int e1, int e3, int out, int skip) {
+  int expand_pair(const std::string& p, int in, int e1, int e3, int out, int skip) {
     const TensorInfo ti = g_->tensors[in];
     Op op;
     op.kind = OP_CONV;
@@ -265,6 +269,7 @@ class GraphBuilder {
     op.sub[1] = conv_sub(p + "/expand3x3", 3, 3, ti.C, e3, true, p + "/expand3x3_bn", 1, e1);
     g_->alg_macs += (int64_t)ti.H * ti.W * ti.C * (e1 + 9 * e3);
     push(op);
+    return (int)g_->ops.size() - 1;
   }
 
   // Conv2DTranspose (1,4)/(1,2) SAME (+bias) (+BN) (+act): o = 2i + k - 1, so
@@ -305,6 +310,23 @@ class GraphBuilder {
     }
     push(op);
     return out;
+  }
+
+  // Whole Context Aggregation Module as one fused kernel (C = 64 or 128).
+  int cam_fused(const std::string& p, int x) {
+    const TensorInfo ti = g_->tensors[x];
+    const int C = ti.C, R = C / 16;
+    Op op;
+    op.kind = OP_CAM;
+    op.in = x;
+    op.cin_t = op.cin_k = C;
+    op.nsub = 2;
+    op.sub[0] = conv_sub(p + "/squeeze", 1, 1, C, R, true, p + "/squeeze_bn", 1, 0);
+    op.sub[1] = conv_sub(p + "/excitation", 1, 1, R, C, true, p + "/excitation_bn", 3, 0);
+    op.out = tensor(p, ti.H, ti.W, C);
+    g_->alg_macs += (int64_t)ti.H * ti.W * 2 * C * R;
+    push(op);
+    return op.out;
   }
 
   // MaxPool SAME; k x k windows with k > 3 run as two separable passes (1xk then kx1).
@@ -376,6 +398,11 @@ inline void build_squeezesegv2(Graph* g) {
 
   auto cam = [&](const std::string& p, int x) {
     const int C = g->tensors[x].C;
+    if (C == 64 || C == 128) {
+      const int out = b.cam_fused(p, x);
+      b.module_bytes(b.fl(x), b.fl(out));
+      return out;
+    }
     const int pooled = b.pool(p + "/pool", x, 7, 1);
     const int sq = b.conv(p + "/squeeze", pooled, 1, 1, C / 16, 1, true, p + "/squeeze_bn", 1);
     // excitation -> BN -> sigmoid, gate multiplies the un-pooled input (:69-70)
@@ -384,12 +411,14 @@ inline void build_squeezesegv2(Graph* g) {
     b.module_bytes(b.fl(x), b.fl(out));
     return out;
   };
-  auto fire = [&](const std::string& p, int x, int sq_c, int e1, int e3, bool up, int skip) {
+  int last_expand = -1;
+  auto fire = [&](const std::string& p, int x, int sq_c, int e1, int e3, bool up, int skip,
+                  int64_t skip_floats = 0) {
     int s = b.conv(p + "/squeeze", x, 1, 1, sq_c, 1, true, p + "/squeeze_bn", 1);
     if (up) s = b.deconv(p + "/upconv", s, sq_c, "", 1);  // ReLU, no BN (:194)
     const int out = b.tensor(p, g->tensors[s].H, g->tensors[s].W, e1 + e3);
-    b.expand_pair(p, s, e1, e3, out, skip);
-    b.module_bytes(b.fl(x) + (skip >= 0 ? b.fl(skip) : 0), b.fl(out));
+    last_expand = b.expand_pair(p, s, e1, e3, out, skip);
+    b.module_bytes(b.fl(x) + (skip >= 0 ? b.fl(skip) : skip_floats), b.fl(out));
     return out;
   };
   auto pool = [&](const std::string& p, int x) {
@@ -401,9 +430,11 @@ inline void build_squeezesegv2(Graph* g) {
   int x = b.conv("conv1", x_in, 3, 3, 64, 2, true, "bn1", 1, -1, 0, -1, false, -1, 6);  // :289
   b.module_bytes(b.fl(x_in, 6), b.fl(x));
   const int cam1 = cam("cam1", x);                                                          // :291
-  const int skip = b.conv("conv1_skip", x_in, 1, 1, 64, 1, true, "bn1_skip", 0, -1, 0, -1, false,
-                          -1, 6);                                                           // :293
-  b.module_bytes(b.fl(x_in, 6), b.fl(skip));
+  // conv1_skip + bn1_skip (:293) are not materialised: the 1x1 conv of the 6-channel input is
+  // evaluated inside fire13's epilogue (:319).  ALG_BYTES still counts the reference's module.
+  const SubOp skip_sub = b.conv_sub("conv1_skip", 1, 1, 6, 64, true, "bn1_skip", 0, 0);
+  g->alg_macs += (int64_t)H * W * 6 * 64;
+  b.module_bytes(b.fl(x_in, 6), (int64_t)H * W * 64);
   x = pool("pool1", cam1);                                                                  // :295
   x = fire("fire2", x, 16, 64, 64, false, -1);
   x = cam("cam2", x);
@@ -420,7 +451,10 @@ inline void build_squeezesegv2(Graph* g) {
   x = fire("fire10", x, 64, 128, 128, true, fire5);                                         // :312-313
   x = fire("fire11", x, 32, 64, 64, true, cam3);                                            // :314-315
   x = fire("fire12", x, 16, 32, 32, true, cam1);                                            // :316-317
-  x = fire("fire13", x, 16, 32, 32, true, skip);                                            // :318-319
+  x = fire("fire13", x, 16, 32, 32, true, -1, (int64_t)H * W * 64);                         // :318-319
+  g->ops[last_expand].sk_in = x_in;
+  g->ops[last_expand].sk = skip_sub;
+  b.touch(x_in, last_expand);
   b.head("conv14", x, NC);                                                                  // :323-325
   b.module_bytes(b.fl(x), (int64_t)H * W, (int64_t)H * W);  // + mask 1 B/px, int32 preds out
 }
@@ -538,7 +572,7 @@ inline void plan_workspace(Graph* g) {
 inline int resolve_micro_batch(const pclseg_desc& d) {
   if (d.micro_batch > 0) return d.micro_batch;
   const int64_t px = (int64_t)d.height * d.width;
-  int64_t mb = (int64_t)(1 << 19) / std::max<int64_t>(px, 1);
+  int64_t mb = (int64_t)(1 << 20) / std::max<int64_t>(px, 1);
   return (int)std::min<int64_t>(std::max<int64_t>(mb, 1), 16);
 }
 
@@ -586,6 +620,18 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
   // packed-parameter geometry: exact-f32 fragments, split-f16 fragments, biases
   for (Op& op : g->ops) {
     if (op.kind == OP_POOL) continue;
+    if (op.sk_in >= 0) {  // [8][C] + [C]
+      op.sk.b_off = g->packed_bias_floats;
+      g->packed_bias_floats += (int64_t)9 * op.sk.cout;
+    }
+    if (op.kind == OP_CAM) {  // plain [C][R]+[R] and [R][C]+[C] float32 blocks
+      const int C = op.cin_t, R = C / 16;
+      op.sub[0].b_off = g->packed_bias_floats;
+      g->packed_bias_floats += (int64_t)C * R + R;
+      op.sub[1].b_off = g->packed_bias_floats;
+      g->packed_bias_floats += (int64_t)R * C + C;
+      continue;
+    }
     op_geometry(&op);
     for (int i = 0; i < op.nsub; ++i) {
       SubOp& su = op.sub[i];

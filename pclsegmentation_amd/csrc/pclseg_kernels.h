@@ -59,6 +59,8 @@ struct ConvArgs {
   float* out;         // [N,H,Wout,out_C]
   const float* res1;  // optional, [N,H,Wout,res1_C], read at co_off + co
   const float* res2;  // optional
+  const float* skx;   // optional fused skip branch: BN(conv1x1(skx)) added after the activation;
+  const float* skw;   //   skx [N,H,Wout,8], skw = [8][out_C] folded weights then [out_C] bias
   const uint8_t* mask;  // head only
   int32_t* preds;       // head only
   float* probs;         // head only, optional
@@ -348,6 +350,24 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
             v = a.res1_mul ? v * r : v + r;
           }
           if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_C + S.co_off + co);
+          if (a.skx) {
+            // SqueezeSegV2's conv1_skip + bn1_skip (nets/SqueezeSegV2.py:293,319) evaluated here
+            // from the 8-channel network input instead of round-tripping a 64-channel tensor
+            const float* wp = a.skw + S.co_off + co;
+            f32x4 z = *reinterpret_cast<const f32x4*>(wp + 8 * a.out_C);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.skx + pix * 8);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.skx + pix * 8 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 w0v = *reinterpret_cast<const f32x4*>(wp + c * a.out_C);
+              const f32x4 w1v = *reinterpret_cast<const f32x4*>(wp + (4 + c) * a.out_C);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) z[e] = fmaf(x0[c], w0v[e], z[e]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) z[e] = fmaf(x1[c], w1v[e], z[e]);
+            }
+            v += z;
+          }
           *reinterpret_cast<f32x4*>(a.out + pix * a.out_C + S.co_off + co) = v;
         }
       }
@@ -409,6 +429,169 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
         bi = pbi;
       }
       if (g == 0 && valid) a.preds[pix] = a.mask[pix] ? bi : a.none_index;
+    }
+  }
+}
+
+// ---- Context Aggregation Module, one kernel (reference: nets/SqueezeSegV2.py:30-70)
+//   out = x * sigmoid(BN(W2 . relu(BN(W1 . maxpool7x7_s1_SAME(x)))))          C -> C/16 -> C
+// A block owns an 8x32 pixel tile.  Channels are swept in chunks of 16: the (8+6)x(32+6) halo
+// patch goes to LDS (-inf outside the image: padding never wins), the 7x7 max is taken separably
+// (row pass LDS->LDS, column pass LDS->registers) and each thread folds its pooled channel quad
+// into partial squeeze sums.  The next chunk's global loads are in flight during both passes.
+// The gate is then applied in a second, fully coalesced sweep over the tile's own pixels.
+// Everything is float32 on the VALU (the two 1x1 convs are 2*C*C/16 MACs per pixel).
+struct CamArgs {
+  const float* x;   // [N,H,W,C]
+  float* out;       // [N,H,W,C]
+  const float* w1;  // [C][R]  BN-folded squeeze weights
+  const float* b1;  // [R]
+  const float* w2;  // [R][C]  BN-folded excitation weights
+  const float* b2;  // [C]
+  int N, H, W, tilesH, tilesW;
+};
+
+constexpr int kCamTH = 8, kCamTW = 32, kCamPH = kCamTH + 6, kCamPW = kCamTW + 6, kCamCK = 16;
+constexpr int kCamPatchFloats = kCamPH * kCamPW * kCamCK;  // 8512
+constexpr int kCamTmpFloats = kCamPH * kCamTW * kCamCK;    // 7168
+constexpr int kCamStage = (kCamPH * kCamPW * (kCamCK / 4) + 255) / 256;  // float4 loads per thread = 9
+
+template <int C, int R>
+__global__ __launch_bounds__(256) void cam_kernel(const CamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* patch = reinterpret_cast<float*>(smem_raw);
+  float* tmp = patch + kCamPatchFloats;
+  float* w1c = tmp + kCamTmpFloats;  // [16][R]
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int twi = tile % a.tilesW;
+  tile /= a.tilesW;
+  const int thi = tile % a.tilesH;
+  const int n = tile / a.tilesH;
+  const int h0 = thi * kCamTH, w0 = twi * kCamTW;
+  const float* xn = a.x + (size_t)n * a.H * a.W * C;
+  const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+
+  // staging assignment: item = (patch pixel, channel quad), quad fastest
+  const int sq = tid & 3;
+  auto stage_load = [&](int chunk, f32x4 (&v)[kCamStage]) {
+#pragma unroll
+    for (int k = 0; k < kCamStage; ++k) {
+      const int pix = (tid >> 2) + k * 64;
+      const int pr = pix / kCamPW, pc = pix - pr * kCamPW;
+      const int h = h0 - 3 + pr, w = w0 - 3 + pc;
+      const bool ok = pix < kCamPH * kCamPW && h >= 0 && h < a.H && w >= 0 && w < a.W;
+      const float* src = ok ? xn + ((size_t)h * a.W + w) * C + chunk * kCamCK + sq * 4 : xn;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+      v[k] = ok ? t : ninf;
+    }
+  };
+
+  // squeeze partial sums: this thread owns channel quad `sq` of pixels (tid>>2) + 64*it
+  float sp[4][R];
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int r = 0; r < R; ++r) sp[it][r] = 0.f;
+
+  f32x4 v[kCamStage];
+  stage_load(0, v);
+  constexpr int NCH = C / kCamCK;
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < kCamStage; ++k) {
+      const int pix = (tid >> 2) + k * 64;
+      if (pix < kCamPH * kCamPW) *reinterpret_cast<f32x4*>(patch + pix * kCamCK + sq * 4) = v[k];
+    }
+    if (tid < kCamCK * R / 4)  // this chunk's squeeze weights: rows chunk*16 .. +15 of [C][R]
+      *reinterpret_cast<f32x4*>(w1c + tid * 4) =
+          *reinterpret_cast<const f32x4*>(a.w1 + (size_t)chunk * kCamCK * R + tid * 4);
+    __syncthreads();
+    if (chunk + 1 < NCH) stage_load(chunk + 1, v);
+    // row pass: tmp[pr][tc][q] = max_j patch[pr][tc + j][q]
+#pragma unroll
+    for (int it = 0; it < (kCamPH * kCamTW * 4) / 256; ++it) {
+      const int idx = it * 256 + tid;
+      const int q = idx & 3, tc = (idx >> 2) & 31, pr = idx >> 7;
+      const float* src = patch + (pr * kCamPW + tc) * kCamCK + q * 4;
+      f32x4 m = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int j = 1; j < 7; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + j * kCamCK);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
+      }
+      *reinterpret_cast<f32x4*>(tmp + (pr * kCamTW + tc) * kCamCK + q * 4) = m;
+    }
+    __syncthreads();
+    // column pass + squeeze partial sums
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int px = (tid >> 2) + it * 64;
+      const int tr = px >> 5, tc = px & 31;
+      const float* src = tmp + (tr * kCamTW + tc) * kCamCK + sq * 4;
+      f32x4 m = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int i = 1; i < 7; ++i) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + i * kCamTW * kCamCK);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wr = w1c + (sq * 4 + e) * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) sp[it][r] = fmaf(m[e], wr[r], sp[it][r]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // finish the squeeze: sum the 4 quad-lanes of each pixel, + bias, ReLU -> LDS s[256][R]
+  float* s_lds = patch;           // [256][R]
+  float* w2_lds = patch + 256 * R;  // [R][C]
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float t = sp[it][r];
+      t += __shfl_xor(t, 1);
+      t += __shfl_xor(t, 2);
+      sp[it][r] = fmaxf(t + a.b1[r], 0.f);
+    }
+    if (sq == 0) {
+      const int px = (tid >> 2) + it * 64;
+#pragma unroll
+      for (int r = 0; r < R; ++r) s_lds[px * R + r] = sp[it][r];
+    }
+  }
+  for (int i = tid; i < R * C / 4; i += 256)
+    *reinterpret_cast<f32x4*>(w2_lds + i * 4) = *reinterpret_cast<const f32x4*>(a.w2 + i * 4);
+  __syncthreads();
+
+  // gate sweep: item = (tile pixel, channel quad), quad fastest -> C*4 contiguous bytes per pixel
+  constexpr int Q = C / 4;
+  float* outn = a.out + (size_t)n * a.H * a.W * C;
+#pragma unroll 4
+  for (int it = 0; it < Q; ++it) {
+    const int idx = it * 256 + tid;
+    const int q = idx % Q, px = idx / Q;
+    const int h = h0 + (px >> 5), w = w0 + (px & 31);
+    if (h < a.H && w < a.W) {
+      const size_t off = ((size_t)h * a.W + w) * C + q * 4;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + off);
+      f32x4 z = *reinterpret_cast<const f32x4*>(a.b2 + q * 4);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float sr = s_lds[px * R + r];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w2_lds + r * C + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = fmaf(sr, wv[e], z[e]);
+      }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = xv[e] * (1.0f / (1.0f + expf(-z[e])));
+      *reinterpret_cast<f32x4*>(outn + off) = o;
     }
   }
 }
