@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -42,8 +43,16 @@ struct pclseg_handle {
   _Float16* d_w16 = nullptr;   // split-f16 weight fragments
   float* d_bias = nullptr;     // folded biases
   bool exact = false;
-  float* d_arena = nullptr;
-  uint8_t* d_mask = nullptr;  // micro-batch mask when the caller gives none
+  // Micro-batches are independent, so they are dealt round-robin to `nlanes` lanes, each with
+  // its own activation arena and HIP stream: kernels of different micro-batches overlap on the
+  // GPU (a memory-bound kernel of one fills the idle pipes of a latency-bound kernel of another).
+  static constexpr int kMaxLanes = 8;
+  int nlanes = 1;
+  float* d_arena_lane[kMaxLanes] = {nullptr};
+  uint8_t* d_mask_lane[kMaxLanes] = {nullptr};
+  hipStream_t lane_stream[kMaxLanes] = {nullptr};
+  hipEvent_t ev_in = nullptr, ev_lane[kMaxLanes] = {nullptr};
+  float* d_arena = nullptr;   // arena of the lane that ran the LAST micro-batch (debug reads)
   // host-mode staging (grown on demand)
   void* d_stage_in = nullptr;   size_t stage_in_bytes = 0;
   uint8_t* d_stage_mask = nullptr; size_t stage_mask_bytes = 0;
@@ -254,25 +263,27 @@ int ensure(pclseg_handle* h, void** p, size_t* have, size_t need) {
 }
 
 // One sweep of the network over `cnt` scans already present in the arena's input tensor.
-int run_ops(pclseg_handle* h, int cnt, const uint8_t* mask, int32_t* preds, float* probs,
+int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* preds, float* probs,
             float* logits) {
   const Graph& g = h->g;
+  float* const arena = h->d_arena_lane[lane];
+  const hipStream_t stream = h->nlanes > 1 ? h->lane_stream[lane] : h->stream;
   for (const Op& op : g.ops) {
     const TensorInfo& ti = g.tensors[op.in];
-    const float* in = h->d_arena + ti.offset;
+    const float* in = arena + ti.offset;
     if (op.kind == OP_POOL) {
-      float* out = h->d_arena + g.tensors[op.out].offset;
-      HIP_TRY(h, launch_pool(in, out, cnt, ti.H, ti.W, ti.C, op.pool_kh, op.pool_kw, op.sw, h->stream));
+      float* out = arena + g.tensors[op.out].offset;
+      HIP_TRY(h, launch_pool(in, out, cnt, ti.H, ti.W, ti.C, op.pool_kh, op.pool_kw, op.sw, stream));
       continue;
     }
     if (op.kind == OP_CAM) {
       CamArgs c;
       c.x = in;
-      c.out = h->d_arena + g.tensors[op.out].offset;
+      c.out = arena + g.tensors[op.out].offset;
       const int C = op.cin_t, R = C / 16;
       c.w1 = h->d_bias + op.sub[0].b_off; c.b1 = c.w1 + (size_t)C * R;
       c.w2 = h->d_bias + op.sub[1].b_off; c.b2 = c.w2 + (size_t)R * C;
-      HIP_TRY(h, launch_cam(c, cnt, ti.H, ti.W, C, h->stream));
+      HIP_TRY(h, launch_cam(c, cnt, ti.H, ti.W, C, stream));
       continue;
     }
     ConvArgs a;
@@ -286,13 +297,13 @@ int run_ops(pclseg_handle* h, int cnt, const uint8_t* mask, int32_t* preds, floa
       a.none_index = g.desc.none_index;
     } else {
       const TensorInfo& to = g.tensors[op.out];
-      a.out = h->d_arena + to.offset;
+      a.out = arena + to.offset;
       a.out_C = to.C;
-      if (op.res1 >= 0) { a.res1 = h->d_arena + g.tensors[op.res1].offset; a.res1_C = g.tensors[op.res1].C; }
-      if (op.res2 >= 0) { a.res2 = h->d_arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
-      if (op.sk_in >= 0) { a.skx = h->d_arena + g.tensors[op.sk_in].offset; a.skw = h->d_bias + op.sk.b_off; }
+      if (op.res1 >= 0) { a.res1 = arena + g.tensors[op.res1].offset; a.res1_C = g.tensors[op.res1].C; }
+      if (op.res2 >= 0) { a.res2 = arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
+      if (op.sk_in >= 0) { a.skx = arena + g.tensors[op.sk_in].offset; a.skw = h->d_bias + op.sk.b_off; }
     }
-    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, h->exact, h->stream));
+    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, h->exact, stream));
   }
   return PCLSEG_OK;
 }
@@ -338,30 +349,45 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
     d_mask_out = mask_out ? h->d_stage_mask : nullptr;
   }
 
-  float* d_lidar8 = h->d_arena + g.tensors[g.t_input].offset;
   NormArgs na;
   for (int i = 0; i < 5; ++i) { na.mean[i] = g.desc.mean[i]; na.std[i] = g.desc.std[i]; }
-  for (int s0 = 0; s0 < n; s0 += g.micro_batch) {
+  const bool multi = h->nlanes > 1;
+  if (multi) {  // lanes start after everything already queued on the caller's stream (inputs)
+    HIP_TRY(h, hipEventRecord(h->ev_in, h->stream));
+    for (int l = 0; l < h->nlanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_in, 0));
+  }
+  int mbi = 0;
+  for (int s0 = 0; s0 < n; s0 += g.micro_batch, ++mbi) {
     const int cnt = std::min(g.micro_batch, n - s0);
     const size_t P = (size_t)cnt * HW;
+    const int lane = mbi % h->nlanes;
+    const hipStream_t stream = multi ? h->lane_stream[lane] : h->stream;
+    float* d_lidar8 = h->d_arena_lane[lane] + g.tensors[g.t_input].offset;
     const uint8_t* mask_mb;
     if (raw) {
-      uint8_t* mdst = d_mask_out ? d_mask_out + (size_t)s0 * HW : h->d_mask;
-      hipLaunchKernelGGL(normalize_kernel<8>, dim3(stream_blocks(P)), dim3(256), 0, h->stream,
+      uint8_t* mdst = d_mask_out ? d_mask_out + (size_t)s0 * HW : h->d_mask_lane[lane];
+      hipLaunchKernelGGL(normalize_kernel<8>, dim3(stream_blocks(P)), dim3(256), 0, stream,
                          d_in + (size_t)s0 * HW * 5, d_lidar8, mdst, P, na);
       HIP_TRY(h, hipGetLastError());
       mask_mb = mdst;
     } else {
-      hipLaunchKernelGGL(pad6to8_kernel, dim3(stream_blocks(P)), dim3(256), 0, h->stream,
+      hipLaunchKernelGGL(pad6to8_kernel, dim3(stream_blocks(P)), dim3(256), 0, stream,
                          d_in + (size_t)s0 * HW * 6, d_lidar8, P);
       HIP_TRY(h, hipGetLastError());
       mask_mb = d_mask_in + (size_t)s0 * HW;
     }
-    int rc = run_ops(h, cnt, mask_mb, d_preds + (size_t)s0 * HW,
+    int rc = run_ops(h, lane, cnt, mask_mb, d_preds + (size_t)s0 * HW,
                      d_probs ? d_probs + (size_t)s0 * HW * NC : nullptr,
                      d_logits ? d_logits + (size_t)s0 * HW * NC : nullptr);
     if (rc) return rc;
     h->last_count = cnt;
+    h->d_arena = h->d_arena_lane[lane];
+  }
+  if (multi) {  // the caller's stream continues only after every lane has drained
+    for (int l = 0; l < h->nlanes; ++l) {
+      HIP_TRY(h, hipEventRecord(h->ev_lane[l], h->lane_stream[l]));
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_lane[l], 0));
+    }
   }
   if (mem == PCLSEG_MEM_HOST) {
     HIP_TRY(h, hipMemcpyAsync(preds, d_preds, n * HW * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -471,13 +497,29 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
   if ((e = hipSetDevice(desc->device)) != hipSuccess)
     return bail(PCLSEG_ERR_HIP, fmt("hipSetDevice(%d): %s", desc->device, hipGetErrorString(e)));
   const size_t arena_bytes = (size_t)h->g.arena_floats * sizeof(float);
-  if ((e = hipMalloc((void**)&h->d_arena, arena_bytes)) != hipSuccess)
-    return bail(e == hipErrorOutOfMemory ? PCLSEG_ERR_OOM : PCLSEG_ERR_HIP,
-                fmt("hipMalloc(%zu B activation arena): %s", arena_bytes, hipGetErrorString(e)));
-  (void)hipMemset(h->d_arena, 0, arena_bytes);
   const size_t mask_bytes = (size_t)h->g.micro_batch * desc->height * desc->width;
-  if ((e = hipMalloc((void**)&h->d_mask, mask_bytes)) != hipSuccess)
-    return bail(PCLSEG_ERR_HIP, fmt("hipMalloc(mask): %s", hipGetErrorString(e)));
+  {
+    const char* env = getenv("PCLSEG_LANES");  // tuning override
+    int lanes = env ? atoi(env) : 2;
+    if (desc->flags & PCLSEG_FLAG_KEEP_ACTIVATIONS) lanes = 1;  // debug reads need one arena
+    h->nlanes = std::max(1, std::min(lanes, (int)pclseg_handle::kMaxLanes));
+  }
+  for (int l = 0; l < h->nlanes; ++l) {
+    if ((e = hipMalloc((void**)&h->d_arena_lane[l], arena_bytes)) != hipSuccess)
+      return bail(e == hipErrorOutOfMemory ? PCLSEG_ERR_OOM : PCLSEG_ERR_HIP,
+                  fmt("hipMalloc(%zu B activation arena): %s", arena_bytes, hipGetErrorString(e)));
+    (void)hipMemset(h->d_arena_lane[l], 0, arena_bytes);
+    if ((e = hipMalloc((void**)&h->d_mask_lane[l], mask_bytes)) != hipSuccess)
+      return bail(PCLSEG_ERR_HIP, fmt("hipMalloc(mask): %s", hipGetErrorString(e)));
+    if (h->nlanes > 1) {
+      if ((e = hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking)) != hipSuccess ||
+          (e = hipEventCreateWithFlags(&h->ev_lane[l], hipEventDisableTiming)) != hipSuccess)
+        return bail(PCLSEG_ERR_HIP, fmt("stream/event creation: %s", hipGetErrorString(e)));
+    }
+  }
+  if (h->nlanes > 1 && (e = hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming)) != hipSuccess)
+    return bail(PCLSEG_ERR_HIP, fmt("event creation: %s", hipGetErrorString(e)));
+  h->d_arena = h->d_arena_lane[0];
   h->exact = (desc->flags & PCLSEG_FLAG_EXACT_F32) != 0;
   if (h->exact) e = hipMalloc((void**)&h->d_w32, (size_t)h->g.packed32_floats * sizeof(float));
   else e = hipMalloc((void**)&h->d_w16, (size_t)h->g.packed16_halfs * sizeof(_Float16));
@@ -491,8 +533,15 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
 
 int pclseg_destroy(pclseg_handle* h) {
   if (!h) return PCLSEG_OK;
-  if (h->d_arena || h->d_bias) (void)hipSetDevice(h->device);
-  void* bufs[] = {h->d_arena, h->d_w32, h->d_w16, h->d_bias, h->d_mask, h->d_stage_in, h->d_stage_mask,
+  if (h->d_arena_lane[0] || h->d_bias) (void)hipSetDevice(h->device);
+  for (int l = 0; l < pclseg_handle::kMaxLanes; ++l) {
+    if (h->lane_stream[l]) { (void)hipStreamSynchronize(h->lane_stream[l]); (void)hipStreamDestroy(h->lane_stream[l]); }
+    if (h->ev_lane[l]) (void)hipEventDestroy(h->ev_lane[l]);
+    if (h->d_arena_lane[l]) (void)hipFree(h->d_arena_lane[l]);
+    if (h->d_mask_lane[l]) (void)hipFree(h->d_mask_lane[l]);
+  }
+  if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+  void* bufs[] = {h->d_w32, h->d_w16, h->d_bias, h->d_stage_in, h->d_stage_mask,
                   h->d_stage_preds, h->d_stage_probs, h->d_stage_logits};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
