@@ -43,7 +43,9 @@ def cpu_baseline(model_name, mc, weights, h, w, pvalid, budget_s):
   from oracle import np_oracle as O
   from oracle.torch_ref import TorchNet
   from pclsegmentation_amd.utils.synthetic import synthetic_scans
-  cores = os.cpu_count() or 1
+  # oneDNN scales poorly past a few dozen threads on these small convolutions (256 threads ran
+  # 20x slower than 8 on the GPU box), so the pool is capped; `cores` reports the threads used
+  cores = min(os.cpu_count() or 1, 32)
   torch.set_num_threads(cores)
   net = TorchNet(model_name, weights, num_layers=mc.get("NUM_LAYERS"),
                  output_stride=mc.get("OUTPUT_STRIDE", 16))
@@ -166,7 +168,7 @@ def main():
       "data": "synthetic",
       "config": {"workload": args.workload, "model": model_name, "shape": [h, w],
                  "num_class": mc.NUM_CLASS, "batch_per_gpu": batch, "global_batch": batch * world,
-                 "micro_batch": info["micro_batch"], "parallelism": "batch-sharded x%d" % world},
+                 "math": "f16x3 products, f32 accumulate", "micro_batch": info["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "2")), "parallelism": "batch-sharded x%d" % world},
       "roofline": roof,
     }
     if world == 1 and args.cpu_seconds > 0:

@@ -133,3 +133,31 @@ def test_idempotent_and_deterministic(cuda):
   a = run_engine(model, raw)
   b = run_engine(model, raw)
   assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_inference_cli_writes_reference_outputs(cuda, tmp_path):
+  """The CLI keeps the reference's flags and per-scan outputs (reference: inference.py:81-112):
+  pred_<name>.npy int32 [H,W], plot_<name>.png and plot_gt_<name>.png (RGBA)."""
+  from PIL import Image
+  from pclsegmentation_amd import inference as cli
+  g = np.load(os.path.join(GOLDEN, "model_ssv2_real_32x240.npz"))
+  src = tmp_path / "scans"
+  src.mkdir()
+  for i in range(2):   # real scans of the reference's sample dataset, with their label channel
+    sample = np.concatenate([g["raw"][i], g["labels"][i][..., None].astype(np.float32)], -1)
+    np.save(str(src / ("scan%d.npy" % i)), sample.astype(np.float64))
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  model.save(str(tmp_path / "model.npz"))
+  out = tmp_path / "out"
+  cli.main(["-d", str(src / "*.npy"), "-m", "squeezesegv2", "-t", str(out), "-p", str(tmp_path / "model.npz")])
+  for i in range(2):
+    pred = np.load(str(out / ("pred_scan%d.npy" % i)))
+    assert pred.dtype == np.int32 and pred.shape == (32, 240)
+    decided = g["margin"][i] > MARGIN
+    assert np.array_equal(pred[decided], g["preds"][i][decided])
+    for prefix in ("plot_", "plot_gt_"):
+      img = Image.open(str(out / ("%sscan%d.png" % (prefix, i))))
+      assert img.mode == "RGBA" and img.size == (240, 32)
+    rgb = np.asarray(Image.open(str(out / ("plot_scan%d.png" % i))))[..., :3]
+    assert np.array_equal(rgb, (255 * np.asarray(mc.CLS_COLOR_MAP)[pred]).astype(np.uint8))
