@@ -168,7 +168,7 @@ def main():
       "data": "synthetic",
       "config": {"workload": args.workload, "model": model_name, "shape": [h, w],
                  "num_class": mc.NUM_CLASS, "batch_per_gpu": batch, "global_batch": batch * world,
-                 "math": "f16x3 products, f32 accumulate", "micro_batch": info["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "2")), "parallelism": "batch-sharded x%d" % world},
+                 "math": "f16x3 products, f32 accumulate", "micro_batch": info["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")), "parallelism": "batch-sharded x%d" % world},
       "roofline": roof,
     }
     if world == 1 and args.cpu_seconds > 0:

@@ -500,7 +500,7 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
   const size_t mask_bytes = (size_t)h->g.micro_batch * desc->height * desc->width;
   {
     const char* env = getenv("PCLSEG_LANES");  // tuning override
-    int lanes = env ? atoi(env) : 2;
+    int lanes = env ? atoi(env) : 3;
     if (desc->flags & PCLSEG_FLAG_KEEP_ACTIVATIONS) lanes = 1;  // debug reads need one arena
     h->nlanes = std::max(1, std::min(lanes, (int)pclseg_handle::kMaxLanes));
   }

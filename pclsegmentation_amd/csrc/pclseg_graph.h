@@ -9,6 +9,7 @@
 // stride logic :158-181/:215-231, skip bookkeeping :263-277).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -572,7 +573,7 @@ inline void plan_workspace(Graph* g) {
 inline int resolve_micro_batch(const pclseg_desc& d) {
   if (d.micro_batch > 0) return d.micro_batch;
   const int64_t px = (int64_t)d.height * d.width;
-  int64_t mb = (int64_t)(1 << 20) / std::max<int64_t>(px, 1);
+  int64_t mb = (int64_t)(1 << 19) / std::max<int64_t>(px, 1);
   return (int)std::min<int64_t>(std::max<int64_t>(mb, 1), 16);
 }
 

@@ -39,7 +39,7 @@ constexpr int kConvThreads = 256;  // 4 waves, one per SIMD
 constexpr int kMTW = 4;            // 16-pixel segments per wave
 constexpr int kPadF32 = 4;         // floats of per-pixel LDS padding (bank spread)
 constexpr int kPadF16 = 8;         // halfs of per-pixel LDS padding
-constexpr int kStageBatch = 8;     // global loads a thread keeps in flight while staging
+constexpr int kStageBatch = 4;     // global loads a thread keeps in flight while staging
 
 // A sub-convolution: a window of taps inside the staged patch, with its own weights / bias /
 // activation / destination channel slice / output column phase.
@@ -90,7 +90,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // wave streams from L2 (the block shares one 64-cout group), WN = 1 keeps all couts of a pixel in
 // one wave (needed by the head's argmax) on a 256-pixel block.
 template <int NTW, int WN, bool HEAD, bool F16X3>
-__global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvArgs a) {
       // Weight fragments stream from L2 through a D-deep register ring: the loads of step s+D
       // are issued as soon as step s has consumed its slot, so ~D steps of MFMA work cover the
       // L2 latency (one step ahead is far too little: a step is only 12*NTW MFMAs).
-      constexpr int D = NTW <= 2 ? 4 : 2;
+      constexpr int D = 2;
       f16x8 wh[D][NTW], wl[D][NTW];
 #pragma unroll
       for (int d = 0; d < D; ++d) {
