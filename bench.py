@@ -154,6 +154,12 @@ def main():
     else:
       roof = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": F32_MFMA_PEAK_TF,
               "unit": "TFLOP/s", "frac": round(mfma_tf / F32_MFMA_PEAK_TF, 4), "traffic": None}
+    # measured HBM-side bytes (PMC passes of this same command, committed under profiles/)
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if args.workload == "ssv2_64x2048" and os.path.exists(tpath):
+      t = json.load(open(tpath))
+      roof["traffic"] = int(t["hbm_bytes_per_scan"])
+      roof["traffic_unit"] = "HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/r01_traffic.json"
     roof["kernel"] = "all kernels of one forward step (HIP events on the engine stream)"
     roof["alg_bytes_per_scan"] = alg_bytes
     roof["alg_flops_per_scan"] = alg_flops

@@ -162,9 +162,10 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 
 // ---- launch helpers -------------------------------------------------------------------------
 template <bool HEAD, bool F16>
-hipError_t launch_conv_cfg(int ntw, int wn, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+hipError_t launch_conv_cfg(int mtw, int ntw, int wn, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
 #define PCLSEG_LAUNCH(NTW_, WN_) \
-  hipLaunchKernelGGL((conv_kernel<NTW_, WN_, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a)
+  do { if (mtw == 2) hipLaunchKernelGGL((conv_kernel<2, NTW_, WN_, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); \
+       else hipLaunchKernelGGL((conv_kernel<4, NTW_, WN_, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); } while (0)
   if (wn == 2 && ntw == 2 && !HEAD) { PCLSEG_LAUNCH(2, 2); }
   else if (wn == 1 && ntw == 1) { PCLSEG_LAUNCH(1, 1); }
   else if (wn == 1 && ntw == 2) { PCLSEG_LAUNCH(2, 1); }
@@ -220,10 +221,10 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)ny);
   if (op.kind == OP_HEAD)
-    return exact ? launch_conv_cfg<true, false>(op.ntw, op.wn, grid, lds, s, a)
-                 : launch_conv_cfg<true, true>(op.ntw, op.wn, grid, lds, s, a);
-  return exact ? launch_conv_cfg<false, false>(op.ntw, op.wn, grid, lds, s, a)
-               : launch_conv_cfg<false, true>(op.ntw, op.wn, grid, lds, s, a);
+    return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, grid, lds, s, a)
+                 : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, grid, lds, s, a);
+  return exact ? launch_conv_cfg<false, false>(op.mtw, op.ntw, op.wn, grid, lds, s, a)
+               : launch_conv_cfg<false, true>(op.mtw, op.ntw, op.wn, grid, lds, s, a);
 }
 
 hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {

@@ -36,7 +36,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
 
 constexpr int kConvThreads = 256;  // 4 waves, one per SIMD
-constexpr int kMTW = 4;            // 16-pixel segments per wave
 constexpr int kPadF32 = 4;         // floats of per-pixel LDS padding (bank spread)
 constexpr int kPadF16 = 8;         // halfs of per-pixel LDS padding
 constexpr int kStageBatch = 4;     // global loads a thread keeps in flight while staging
@@ -85,11 +84,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-// Block = 4 waves arranged WM x WN (WM = 4/WN): wave (wm, wn) owns kMTW pixel segments
-// {wm*4 .. wm*4+3} and NTW 16-cout tiles {wn*NTW ..}.  WN = 2 halves the weight fragments each
+// Block = 4 waves arranged WM x WN (WM = 4/WN): wave (wm, wn) owns MTW (2 or 4) pixel segments
+// {wm*MTW ..} and NTW 16-cout tiles {wn*NTW ..}.  WN = 2 halves the weight fragments each
 // wave streams from L2 (the block shares one 64-cout group), WN = 1 keeps all couts of a pixel in
 // one wave (needed by the head's argmax) on a 256-pixel block.
-template <int NTW, int WN, bool HEAD, bool F16X3>
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3>
 __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -111,9 +110,9 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   const ConvSub& S = a.sub[si];
   const int ct0 = (by - (si ? a.sub[0].ny : 0)) * (NTW * WN) + wn * NTW;
 
-  f32x4 acc[kMTW][NTW];
+  f32x4 acc[MTW][NTW];
 #pragma unroll
-  for (int m = 0; m < kMTW; ++m)
+  for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -121,10 +120,10 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   const int npix = a.PH * a.PW;
 
   // this wave's segments: (row, column-segment) inside the tile
-  int seg_r[kMTW], seg_q[kMTW];
+  int seg_r[MTW], seg_q[MTW];
 #pragma unroll
-  for (int m = 0; m < kMTW; ++m) {
-    const int seg = wm * kMTW + m;
+  for (int m = 0; m < MTW; ++m) {
+    const int seg = wm * MTW + m;
     seg_r[m] = seg / a.SEGW;
     seg_q[m] = seg - seg_r[m] * a.SEGW;
   }
@@ -179,9 +178,9 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
           f32x4 wv[NTW];
 #pragma unroll
           for (int nn = 0; nn < NTW; ++nn) wv[nn] = *reinterpret_cast<const f32x4*>(wb + nn * 256);
-          f32x4 xv[kMTW];
+          f32x4 xv[MTW];
 #pragma unroll
-          for (int m = 0; m < kMTW; ++m) {
+          for (int m = 0; m < MTW; ++m) {
             const int pcol = (seg_q[m] * 16 + p) * a.sw + tw;
             const int prow = seg_r[m] + th;
             xv[m] = *reinterpret_cast<const f32x4*>(smem + (prow * a.PW + pcol) * CS + sk * 16 + g * 4);
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int m = 0; m < kMTW; ++m)
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
               for (int nn = 0; nn < NTW; ++nn)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nn][j], xv[m][j], acc[m][nn], 0, 0, 0);
@@ -215,9 +214,9 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
     const int ntaps = S.nkh * S.nkw;
     const int steps_full = (ntaps * ck8_full + 3) >> 2;
     const int inv_kw = (65536 + S.nkw - 1) / S.nkw;
-    int pixoff[kMTW];
+    int pixoff[MTW];
 #pragma unroll
-    for (int m = 0; m < kMTW; ++m)
+    for (int m = 0; m < MTW; ++m)
       pixoff[m] = ((seg_r[m] + S.th0) * a.PW + (seg_q[m] * 16 + p) * a.sw + S.tw0) * CSh;
 
     const int sq = tid & (qs - 1);        // this thread's channel quad (fixed: 256 % qs == 0)
@@ -295,14 +294,14 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
             const int c8 = kidx - tap * ck8;
             const int ti = (tap * inv_kw) >> 16;
             const int koff = (ti * a.PW + (tap - ti * S.nkw)) * CSh + c8 * 8;
-            f16x8 xh[kMTW], xl[kMTW];
+            f16x8 xh[MTW], xl[MTW];
 #pragma unroll
-            for (int m = 0; m < kMTW; ++m) {
+            for (int m = 0; m < MTW; ++m) {
               xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
               xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
             }
 #pragma unroll
-            for (int m = 0; m < kMTW; ++m)
+            for (int m = 0; m < MTW; ++m)
 #pragma unroll
               for (int nn = 0; nn < NTW; ++nn) {
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][nn], xh[m], acc[m][nn], 0, 0, 0);
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
     bv[nn] = *reinterpret_cast<const f32x4*>(S.bias + (ct0 + nn) * 16 + g * 4);
 
 #pragma unroll
-  for (int m = 0; m < kMTW; ++m) {
+  for (int m = 0; m < MTW; ++m) {
     const int oh = h0 + seg_r[m];
     const int j = w0 + seg_q[m] * 16 + p;
     const bool valid = (oh < a.H) && (j < a.Wconv);
