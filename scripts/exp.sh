@@ -1,8 +1,3 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-run() { echo "== $1 $2"; env $1 python bench.py --steps 5 --warmup 2 --cpu-seconds 0 $2 2>&1 | grep -E "metric|rror" | cut -c60-100; }
-PCLSEG_MTW_HEAD=2 PCLSEG_MTW_WN1=2 PCLSEG_MTW_WN2=2 python -m pytest tests/test_gpu_models.py tests/test_gpu_ops.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -2
-run "A=1" ""
-run "PCLSEG_MTW_HEAD=2" ""
-run "PCLSEG_MTW_HEAD=2 PCLSEG_MTW_WN1=2" ""
-run "PCLSEG_MTW_HEAD=2 PCLSEG_MTW_WN1=2 PCLSEG_MTW_WN2=2" ""
-run "PCLSEG_MTW_WN2=2" ""
+for w in darknet21_32x1024 darknet53_64x2048 ssv2_32x240; do timeout 600 python bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 0 2>&1 | grep -E "metric|rror" | cut -c1-330; done
+PCLSEG_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dn53 -- python3 bench.py --workload darknet53_64x2048 --steps 2 --warmup 1 --cpu-seconds 0 > gpurun_out/dn53.log 2>&1
