@@ -161,19 +161,38 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 }
 
 // ---- launch helpers -------------------------------------------------------------------------
+template <int MTW, int NTW, int WN, bool HEAD, bool F16>
+hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+#define PCLSEG_GO(EPI_) \
+  hipLaunchKernelGGL((conv_kernel<MTW, NTW, WN, HEAD, F16, EPI_>), grid, dim3(kConvThreads), lds, s, a)
+  if constexpr (HEAD) { PCLSEG_GO(0); }
+  else if constexpr (!F16) { PCLSEG_GO(4); }  // exact mode: one catch-all instantiation
+  else {
+    switch (epi) {
+      case 0: PCLSEG_GO(0); break;
+      case 1: PCLSEG_GO(1); break;
+      case 2: PCLSEG_GO(2); break;
+      case 3: PCLSEG_GO(3); break;
+      default: PCLSEG_GO(4); break;
+    }
+  }
+#undef PCLSEG_GO
+  return hipGetLastError();
+}
+
 template <bool HEAD, bool F16>
-hipError_t launch_conv_cfg(int mtw, int ntw, int wn, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+hipError_t launch_conv_cfg(int mtw, int ntw, int wn, int epi, dim3 grid, size_t lds, hipStream_t s,
+                           const ConvArgs& a) {
 #define PCLSEG_LAUNCH(NTW_, WN_) \
-  do { if (mtw == 2) hipLaunchKernelGGL((conv_kernel<2, NTW_, WN_, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); \
-       else hipLaunchKernelGGL((conv_kernel<4, NTW_, WN_, HEAD, F16>), grid, dim3(kConvThreads), lds, s, a); } while (0)
+  return mtw == 2 ? launch_conv_epi<2, NTW_, WN_, HEAD, F16>(epi, grid, lds, s, a) \
+                  : launch_conv_epi<4, NTW_, WN_, HEAD, F16>(epi, grid, lds, s, a)
   if (wn == 2 && ntw == 2 && !HEAD) { PCLSEG_LAUNCH(2, 2); }
   else if (wn == 1 && ntw == 1) { PCLSEG_LAUNCH(1, 1); }
   else if (wn == 1 && ntw == 2) { PCLSEG_LAUNCH(2, 1); }
   else if (wn == 1 && ntw == 3) { PCLSEG_LAUNCH(3, 1); }
-  else if (wn == 1 && ntw == 4) { PCLSEG_LAUNCH(4, 1); }
-  else return hipErrorInvalidValue;
+  else if (wn == 1 && ntw == 4 && HEAD) { PCLSEG_LAUNCH(4, 1); }
 #undef PCLSEG_LAUNCH
-  return hipGetLastError();
+  return hipErrorInvalidValue;
 }
 
 // Fill the geometry of `a` (tensor pointers already set) from `op` and launch.
@@ -220,11 +239,12 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)ny);
+  const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
   if (op.kind == OP_HEAD)
-    return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, grid, lds, s, a)
-                 : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, grid, lds, s, a);
-  return exact ? launch_conv_cfg<false, false>(op.mtw, op.ntw, op.wn, grid, lds, s, a)
-               : launch_conv_cfg<false, true>(op.mtw, op.ntw, op.wn, grid, lds, s, a);
+    return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
+                 : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);
+  return exact ? launch_conv_cfg<false, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
+               : launch_conv_cfg<false, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);
 }
 
 hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {

@@ -88,7 +88,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // {wm*MTW ..} and NTW 16-cout tiles {wn*NTW ..}.  WN = 2 halves the weight fragments each
 // wave streams from L2 (the block shares one 64-cout group), WN = 1 keeps all couts of a pixel in
 // one wave (needed by the head's argmax) on a 256-pixel block.
-template <int MTW, int NTW, int WN, bool HEAD, bool F16X3>
+// EPI: which epilogue operands this instantiation carries registers for:
+//   0 none, 1 res1, 2 res1 + res2, 3 fused skip branch (skx), 4 all of them.
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI>
 __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -328,49 +330,95 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   for (int nn = 0; nn < NTW; ++nn)
     bv[nn] = *reinterpret_cast<const f32x4*>(S.bias + (ct0 + nn) * 16 + g * 4);
 
+  if constexpr (!HEAD) {
+    // vmcnt retires loads AND stores in issue order, so a residual load issued after a store
+    // would wait for that store's acknowledgement: tile after tile, the epilogue would pay a full
+    // memory round trip each.  Hence two passes: every residual / skip operand of the whole
+    // accumulator tile is fetched first, then all tiles are finished and stored back to back.
+    constexpr bool kR1 = EPI == 1 || EPI == 2 || EPI == 4;
+    constexpr bool kR2 = EPI == 2 || EPI == 4;
+    constexpr bool kSk = EPI == 3 || EPI == 4;
+    f32x4 r1[kR1 ? MTW : 1][NTW], r2[kR2 ? MTW : 1][NTW], sx0[kSk ? MTW : 1], sx1[kSk ? MTW : 1];
+    size_t pixm[MTW];
+    bool validm[MTW];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    const int oh = h0 + seg_r[m];
-    const int j = w0 + seg_q[m] * 16 + p;
-    const bool valid = (oh < a.H) && (j < a.Wconv);
-    const int ow = j * a.ow_mul + S.ow_off;
-    const size_t pix = ((size_t)n * a.H + oh) * a.Wout + ow;
-
-    if constexpr (!HEAD) {
+    for (int m = 0; m < MTW; ++m) {
+      const int oh = h0 + seg_r[m];
+      const int j = w0 + seg_q[m] * 16 + p;
+      validm[m] = (oh < a.H) && (j < a.Wconv);
+      pixm[m] = ((size_t)n * a.H + oh) * a.Wout + (j * a.ow_mul + S.ow_off);
+    }
+    if constexpr (kR1) if (a.res1) {
 #pragma unroll
-      for (int nn = 0; nn < NTW; ++nn) {
-        const int co = (ct0 + nn) * 16 + g * 4;
-        if (valid && co < S.Cout) {
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NTW; ++nn) {
+          const int co = (ct0 + nn) * 16 + g * 4;
+          const bool ok = validm[m] && co < S.Cout;
+          r1[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res1 + pixm[m] * a.res1_C + S.co_off + co : a.res1);
+        }
+    }
+    if constexpr (kR2) if (a.res2) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NTW; ++nn) {
+          const int co = (ct0 + nn) * 16 + g * 4;
+          const bool ok = validm[m] && co < S.Cout;
+          r2[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res2 + pixm[m] * a.res2_C + S.co_off + co : a.res2);
+        }
+    }
+    if constexpr (kSk) if (a.skx) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const float* xp = validm[m] ? a.skx + pixm[m] * 8 : a.skx;
+        sx0[m] = *reinterpret_cast<const f32x4*>(xp);
+        sx1[m] = *reinterpret_cast<const f32x4*>(xp + 4);
+      }
+    }
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn) {
+      const int co = (ct0 + nn) * 16 + g * 4;
+      // SqueezeSegV2's conv1_skip + bn1_skip (nets/SqueezeSegV2.py:293,319) evaluated here from
+      // the 8-channel network input instead of round-tripping a 64-channel tensor: this lane's
+      // 8x4 weight block + bias (9 quads) is shared by its MTW pixels
+      f32x4 skwv[kSk ? 9 : 1];
+      if constexpr (kSk) if (a.skx && co < S.Cout) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+          skwv[c] = *reinterpret_cast<const f32x4*>(a.skw + S.co_off + co + c * a.out_C);
+      }
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        if (validm[m] && co < S.Cout) {
           f32x4 v = acc[m][nn] + bv[nn];
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
-          if (a.res1) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_C + S.co_off + co);
-            v = a.res1_mul ? v * r : v + r;
-          }
-          if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_C + S.co_off + co);
-          if (a.skx) {
-            // SqueezeSegV2's conv1_skip + bn1_skip (nets/SqueezeSegV2.py:293,319) evaluated here
-            // from the 8-channel network input instead of round-tripping a 64-channel tensor
-            const float* wp = a.skw + S.co_off + co;
-            f32x4 z = *reinterpret_cast<const f32x4*>(wp + 8 * a.out_C);
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.skx + pix * 8);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.skx + pix * 8 + 4);
+          if constexpr (kR1) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
+          if constexpr (kR2) if (a.res2) v += r2[m][nn];
+          if constexpr (kSk) if (a.skx) {
+            f32x4 z = skwv[8];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const f32x4 w0v = *reinterpret_cast<const f32x4*>(wp + c * a.out_C);
-              const f32x4 w1v = *reinterpret_cast<const f32x4*>(wp + (4 + c) * a.out_C);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) z[e] = fmaf(x0[c], w0v[e], z[e]);
+              for (int e = 0; e < 4; ++e) z[e] = fmaf(sx0[m][c], skwv[c][e], z[e]);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) z[e] = fmaf(x1[c], w1v[e], z[e]);
+              for (int e = 0; e < 4; ++e) z[e] = fmaf(sx1[m][c], skwv[4 + c][e], z[e]);
             }
             v += z;
           }
-          *reinterpret_cast<f32x4*>(a.out + pix * a.out_C + S.co_off + co) = v;
+          *reinterpret_cast<f32x4*>(a.out + pixm[m] * a.out_C + S.co_off + co) = v;
         }
       }
-    } else {
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const int oh = h0 + seg_r[m];
+      const int j = w0 + seg_q[m] * 16 + p;
+      const bool valid = (oh < a.H) && (j < a.Wconv);
+      const int ow = j * a.ow_mul + S.ow_off;
+      const size_t pix = ((size_t)n * a.H + oh) * a.Wout + ow;
       // segmentation head (reference: nets/SegmentationNetwork.py:58-69).  The NT tiles hold
       // all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.
       const int NC = S.Cout;
