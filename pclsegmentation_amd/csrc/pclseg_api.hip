@@ -252,7 +252,9 @@ hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {
   c.tilesH = (H + kCamTH - 1) / kCamTH;
   c.tilesW = (W + kCamTW - 1) / kCamTW;
   const dim3 grid((unsigned)(N * c.tilesH * c.tilesW));
-  const size_t lds = (size_t)(kCamPatchFloats + kCamTmpFloats + kCamCK * (C / 16)) * sizeof(float);
+  // chunk buffers, then (aliased after the chunk loop) s[256][R] + w2[R][C]
+  const int R = C / 16;
+  const size_t lds = (size_t)std::max(kCamPatchFloats + kCamTmpFloats + kCamCK * R, 256 * R + R * C) * sizeof(float);
   if (C == 64) hipLaunchKernelGGL((cam_kernel<64, 4>), grid, dim3(256), lds, s, c);
   else if (C == 128) hipLaunchKernelGGL((cam_kernel<128, 8>), grid, dim3(256), lds, s, c);
   else return hipErrorInvalidValue;

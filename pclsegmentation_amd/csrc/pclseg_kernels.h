@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
 
 // ---- Context Aggregation Module, one kernel (reference: nets/SqueezeSegV2.py:30-70)
 //   out = x * sigmoid(BN(W2 . relu(BN(W1 . maxpool7x7_s1_SAME(x)))))          C -> C/16 -> C
-// A block owns an 8x32 pixel tile.  Channels are swept in chunks of 16: the (8+6)x(32+6) halo
+// A block owns an 8x32 pixel tile.  Channels are swept in chunks of kCamCK: the (8+6)x(32+6) halo
 // patch goes to LDS (-inf outside the image: padding never wins), the 7x7 max is taken separably
 // (row pass LDS->LDS, column pass LDS->registers) and each thread folds its pooled channel quad
 // into partial squeeze sums.  The next chunk's global loads are in flight during both passes.
@@ -498,17 +498,25 @@ struct CamArgs {
   int N, H, W, tilesH, tilesW;
 };
 
-constexpr int kCamTH = 8, kCamTW = 32, kCamPH = kCamTH + 6, kCamPW = kCamTW + 6, kCamCK = 16;
-constexpr int kCamPatchFloats = kCamPH * kCamPW * kCamCK;  // 8512
-constexpr int kCamTmpFloats = kCamPH * kCamTW * kCamCK;    // 7168
-constexpr int kCamStage = (kCamPH * kCamPW * (kCamCK / 4) + 255) / 256;  // float4 loads per thread = 9
+constexpr int kCamTH = 8, kCamTW = 32, kCamPH = kCamTH + 6, kCamPW = kCamTW + 6;
+constexpr int kCamCK = 8;  // channels per chunk: 31 KiB of LDS per block -> 5 blocks per CU
+constexpr int kCamPatchFloats = kCamPH * kCamPW * kCamCK;
+constexpr int kCamTmpFloats = kCamPH * kCamTW * kCamCK;
 
 template <int C, int R>
 __global__ __launch_bounds__(256) void cam_kernel(const CamArgs a) {
+  constexpr int CK = kCamCK;
+  constexpr int QP = CK / 4;                 // channel quads per pixel in a chunk (2)
+  constexpr int LQ = QP == 4 ? 2 : 1;        // log2(QP)
+  constexpr int PPR = 256 / QP;              // pixels covered per staging / column round
+  constexpr int NPIX = kCamPH * kCamPW;      // 532 patch pixels
+  constexpr int NSTAGE = (NPIX + PPR - 1) / PPR;
+  constexpr int NROW = kCamPH * kCamTW * QP; // row-pass items
+  constexpr int NCOL = (kCamTH * kCamTW) / PPR;  // column-pass rounds per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* patch = reinterpret_cast<float*>(smem_raw);
   float* tmp = patch + kCamPatchFloats;
-  float* w1c = tmp + kCamTmpFloats;  // [16][R]
+  float* w1c = tmp + kCamTmpFloats;  // [CK][R]
   const int tid = threadIdx.x;
   int tile = blockIdx.x;
   const int twi = tile % a.tilesW;
@@ -520,67 +528,69 @@ __global__ __launch_bounds__(256) void cam_kernel(const CamArgs a) {
   const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
   // staging assignment: item = (patch pixel, channel quad), quad fastest
-  const int sq = tid & 3;
-  auto stage_load = [&](int chunk, f32x4 (&v)[kCamStage]) {
+  const int sq = tid & (QP - 1);
+  auto stage_load = [&](int chunk, f32x4 (&v)[NSTAGE]) {
 #pragma unroll
-    for (int k = 0; k < kCamStage; ++k) {
-      const int pix = (tid >> 2) + k * 64;
+    for (int k = 0; k < NSTAGE; ++k) {
+      const int pix = (tid >> LQ) + k * PPR;
       const int pr = pix / kCamPW, pc = pix - pr * kCamPW;
       const int h = h0 - 3 + pr, w = w0 - 3 + pc;
-      const bool ok = pix < kCamPH * kCamPW && h >= 0 && h < a.H && w >= 0 && w < a.W;
-      const float* src = ok ? xn + ((size_t)h * a.W + w) * C + chunk * kCamCK + sq * 4 : xn;
+      const bool ok = pix < NPIX && h >= 0 && h < a.H && w >= 0 && w < a.W;
+      const float* src = ok ? xn + ((size_t)h * a.W + w) * C + chunk * CK + sq * 4 : xn;
       const f32x4 t = *reinterpret_cast<const f32x4*>(src);
       v[k] = ok ? t : ninf;
     }
   };
 
-  // squeeze partial sums: this thread owns channel quad `sq` of pixels (tid>>2) + 64*it
-  float sp[4][R];
+  // squeeze partial sums: this thread owns channel quad `sq` of pixels (tid>>LQ) + PPR*it
+  float sp[NCOL][R];
 #pragma unroll
-  for (int it = 0; it < 4; ++it)
+  for (int it = 0; it < NCOL; ++it)
 #pragma unroll
     for (int r = 0; r < R; ++r) sp[it][r] = 0.f;
 
-  f32x4 v[kCamStage];
+  f32x4 v[NSTAGE];
   stage_load(0, v);
-  constexpr int NCH = C / kCamCK;
+  constexpr int NCH = C / CK;
   for (int chunk = 0; chunk < NCH; ++chunk) {
 #pragma unroll
-    for (int k = 0; k < kCamStage; ++k) {
-      const int pix = (tid >> 2) + k * 64;
-      if (pix < kCamPH * kCamPW) *reinterpret_cast<f32x4*>(patch + pix * kCamCK + sq * 4) = v[k];
+    for (int k = 0; k < NSTAGE; ++k) {
+      const int pix = (tid >> LQ) + k * PPR;
+      if (pix < NPIX) *reinterpret_cast<f32x4*>(patch + pix * CK + sq * 4) = v[k];
     }
-    if (tid < kCamCK * R / 4)  // this chunk's squeeze weights: rows chunk*16 .. +15 of [C][R]
+    if (tid < CK * R / 4)  // this chunk's squeeze weights: rows chunk*CK .. of [C][R]
       *reinterpret_cast<f32x4*>(w1c + tid * 4) =
-          *reinterpret_cast<const f32x4*>(a.w1 + (size_t)chunk * kCamCK * R + tid * 4);
+          *reinterpret_cast<const f32x4*>(a.w1 + (size_t)chunk * CK * R + tid * 4);
     __syncthreads();
     if (chunk + 1 < NCH) stage_load(chunk + 1, v);
     // row pass: tmp[pr][tc][q] = max_j patch[pr][tc + j][q]
 #pragma unroll
-    for (int it = 0; it < (kCamPH * kCamTW * 4) / 256; ++it) {
+    for (int it = 0; it < (NROW + 255) / 256; ++it) {
       const int idx = it * 256 + tid;
-      const int q = idx & 3, tc = (idx >> 2) & 31, pr = idx >> 7;
-      const float* src = patch + (pr * kCamPW + tc) * kCamCK + q * 4;
-      f32x4 m = *reinterpret_cast<const f32x4*>(src);
+      if (idx < NROW) {
+        const int q = idx & (QP - 1), tc = (idx >> LQ) & 31, pr = idx >> (LQ + 5);
+        const float* src = patch + (pr * kCamPW + tc) * CK + q * 4;
+        f32x4 m = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-      for (int j = 1; j < 7; ++j) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + j * kCamCK);
+        for (int j = 1; j < 7; ++j) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src + j * CK);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
+        }
+        *reinterpret_cast<f32x4*>(tmp + (pr * kCamTW + tc) * CK + q * 4) = m;
       }
-      *reinterpret_cast<f32x4*>(tmp + (pr * kCamTW + tc) * kCamCK + q * 4) = m;
     }
     __syncthreads();
     // column pass + squeeze partial sums
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int px = (tid >> 2) + it * 64;
+    for (int it = 0; it < NCOL; ++it) {
+      const int px = (tid >> LQ) + it * PPR;
       const int tr = px >> 5, tc = px & 31;
-      const float* src = tmp + (tr * kCamTW + tc) * kCamCK + sq * 4;
+      const float* src = tmp + (tr * kCamTW + tc) * CK + sq * 4;
       f32x4 m = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
       for (int i = 1; i < 7; ++i) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + i * kCamTW * kCamCK);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + i * kCamTW * CK);
 #pragma unroll
         for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
       }
@@ -594,20 +604,20 @@ __global__ __launch_bounds__(256) void cam_kernel(const CamArgs a) {
     __syncthreads();
   }
 
-  // finish the squeeze: sum the 4 quad-lanes of each pixel, + bias, ReLU -> LDS s[256][R]
-  float* s_lds = patch;           // [256][R]
+  // finish the squeeze: sum the QP quad-lanes of each pixel, + bias, ReLU -> LDS s[256][R]
+  float* s_lds = patch;             // [256][R]
   float* w2_lds = patch + 256 * R;  // [R][C]
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < NCOL; ++it) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float t = sp[it][r];
       t += __shfl_xor(t, 1);
-      t += __shfl_xor(t, 2);
+      if (QP == 4) t += __shfl_xor(t, 2);
       sp[it][r] = fmaxf(t + a.b1[r], 0.f);
     }
     if (sq == 0) {
-      const int px = (tid >> 2) + it * 64;
+      const int px = (tid >> LQ) + it * PPR;
 #pragma unroll
       for (int r = 0; r < R; ++r) s_lds[px * R + r] = sp[it][r];
     }
