@@ -194,6 +194,15 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
                    const float* kernel, const float* bias, int num_class, int none_index,
                    int32_t* preds, float* probs, float* logits, int math);
 
+/* Evaluation metrics (the row after the forward pass: eval.py:41-58, utils/util.py:64-79,
+ * tf.metrics.MeanIoU as used in nets/SegmentationNetwork.py:52).  Accumulates the confusion
+ * matrix cm[label][pred] += 1 over `count` pixels into a device int64 [num_class, num_class]
+ * buffer (not cleared: call repeatedly to accumulate over a dataset, like update_state).
+ * labels / preds / cm: device pointers; entries outside [0, num_class) are ignored.
+ * Asynchronous on `hip_stream` (NULL = default stream). */
+int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size_t count,
+                               int num_class, int64_t* cm, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

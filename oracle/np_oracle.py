@@ -315,3 +315,40 @@ def forward(arch, weights, lidar, mask, none_index, num_layers=None, output_stri
     logits = darknet_logits(weights, lidar, num_layers, output_stride, dtype, taps)
   prob, pred = segmentation_head(logits, np.asarray(mask, bool), none_index)
   return prob, pred, logits
+
+
+# --------------------------------------------------------------------------- evaluation metrics
+def confusion_matrix(labels, preds, num_class):
+  """tf.metrics.MeanIoU.update_state (reference: eval.py:41-48): total_cm[label][pred] += 1.
+  Exact integer counts; entries outside [0, num_class) are ignored."""
+  l = np.asarray(labels).ravel().astype(np.int64)
+  q = np.asarray(preds).ravel().astype(np.int64)
+  ok = (l >= 0) & (l < num_class) & (q >= 0) & (q < num_class)
+  cm = np.zeros((num_class, num_class), np.int64)
+  np.add.at(cm, (l[ok], q[ok]), 1)
+  return cm
+
+
+def _divide_no_nan(a, b):
+  return np.where(b != 0, a / np.where(b != 0, b, 1), 0.0)
+
+
+def iou_recall_precision(cm):
+  """reference: utils/util.py:64-79 (total_cm rows = labels, columns = predictions)."""
+  cm = np.asarray(cm, np.float64)
+  sum_over_col = cm.sum(axis=1)
+  sum_over_row = cm.sum(axis=0)
+  tp = np.diag(cm)
+  fp = sum_over_row - tp
+  fn = sum_over_col - tp
+  return (_divide_no_nan(tp, tp + fp + fn), _divide_no_nan(tp, tp + fn), _divide_no_nan(tp, tp + fp))
+
+
+def mean_iou(cm):
+  """tf.metrics.MeanIoU.result: mean of the per-class IoU over classes that occur
+  (denominator tp + fp + fn != 0); 0 if none does."""
+  cm = np.asarray(cm, np.float64)
+  tp = np.diag(cm)
+  denom = cm.sum(axis=0) + cm.sum(axis=1) - tp
+  valid = denom != 0
+  return float((_divide_no_nan(tp, denom)).sum() / valid.sum()) if valid.any() else 0.0

@@ -845,4 +845,17 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
   return run_single_op(&op, &f, n, h, w, a, math);
 }
 
+int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size_t count,
+                               int num_class, int64_t* cm, void* hip_stream) {
+  if (!labels || !preds || !cm || num_class < 1 || num_class > 64)
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_confusion_matrix");
+  if (count == 0) return PCLSEG_OK;
+  const unsigned blocks = (unsigned)std::min<size_t>((count + 4095) / 4096, 1024);
+  hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(256), (size_t)num_class * num_class * sizeof(unsigned int),
+                     (hipStream_t)hip_stream, labels, preds, count, num_class,
+                     reinterpret_cast<unsigned long long*>(cm));
+  HIP_TRY(nullptr, hipGetLastError());
+  return PCLSEG_OK;
+}
+
 }  // extern "C"

@@ -732,4 +732,28 @@ __global__ __launch_bounds__(256) void pad6to8_kernel(const float* __restrict__ 
   }
 }
 
+// ---- confusion matrix for the evaluation metrics (reference: eval.py:41-48 ->
+// tf.metrics.MeanIoU.update_state; utils/util.py:64-79).  cm[label][pred] += 1 over all pixels,
+// exact integer counts: per-block histogram in LDS, then one 64-bit atomic per non-zero cell.
+// Entries whose label or prediction is outside [0, NC) are ignored.
+__global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restrict__ labels,
+                                                        const int32_t* __restrict__ preds, size_t count,
+                                                        int NC, unsigned long long* __restrict__ cm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned int* hist = reinterpret_cast<unsigned int*>(smem_raw);
+  const int cells = NC * NC;
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) hist[i] = 0u;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int l = labels[i], q = preds[i];
+    if (l >= 0 && l < NC && q >= 0 && q < NC) atomicAdd(&hist[l * NC + q], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+    const unsigned int v = hist[i];
+    if (v) atomicAdd(&cm[i], (unsigned long long)v);
+  }
+}
+
 }  // namespace pclseg

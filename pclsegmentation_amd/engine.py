@@ -33,6 +33,7 @@ EXPORTS = [
   "pclseg_set_stream", "pclseg_sync", "pclseg_forward", "pclseg_forward_raw",
   "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
   "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
+  "pclseg_op_confusion_matrix",
 ]
 
 
@@ -93,6 +94,7 @@ def load_library():
                                              f32p, f32p, i32, vp, i32]
   lib.pclseg_op_max_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp]
   lib.pclseg_op_head.argtypes = [vp, vp, i32, i32, i32, i32, f32p, f32p, i32, i32, vp, vp, vp, i32]
+  lib.pclseg_op_confusion_matrix.argtypes = [vp, vp, ctypes.c_size_t, i32, vp, vp]
   for name in EXPORTS:
     fn = getattr(lib, name)
     if name not in ("pclseg_last_error",):
@@ -288,3 +290,9 @@ def op_head(x_dev, mask_dev, n, h, w, cin, kernel, bias, none_index, preds_dev, 
   check(load_library().pclseg_op_head(_ptr(x_dev), _ptr(mask_dev), n, h, w, cin, _ptr(k), _ptr(b),
                                       nc, none_index, _ptr(preds_dev), _ptr(probs_dev),
                                       _ptr(logits_dev), MATH[math]))
+
+
+def op_confusion_matrix(labels_dev, preds_dev, count, num_class, cm_dev, stream=0):
+  """cm[label][pred] += 1 (device int64 [NC,NC], accumulating)."""
+  check(load_library().pclseg_op_confusion_matrix(_ptr(labels_dev), _ptr(preds_dev), int(count),
+                                                  int(num_class), _ptr(cm_dev), ctypes.c_void_p(stream or 0)))

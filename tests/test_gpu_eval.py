@@ -1,0 +1,62 @@
+"""Evaluation metrics row: device confusion matrix and the IoU / recall /
+precision / mIoU formulas against the oracle (reference: eval.py:41-58, utils/util.py:64-79)."""
+import os
+
+import numpy as np
+import pytest
+
+import pclsegmentation_amd as P
+from oracle import np_oracle as O
+from pclsegmentation_amd import eval as ev
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("nc,count", [(11, 7680), (20, 131072 * 3 + 17), (2, 5), (64, 100000)])
+def test_confusion_matrix_bit_exact(cuda, nc, count):
+  rng = np.random.default_rng(nc * 7 + count)
+  labels = rng.integers(-1, nc + 1, count).astype(np.int32)    # includes out-of-range ids
+  preds = rng.integers(0, nc, count).astype(np.int32)
+  m = ev.MeanIoU(nc)
+  m.update_state(labels[: count // 2], preds[: count // 2])   # accumulates like update_state
+  m.update_state(labels[count // 2:], preds[count // 2:])
+  want = O.confusion_matrix(labels, preds, nc)
+  assert np.array_equal(m.total_cm, want)
+  assert m.total_cm.sum() == ((labels >= 0) & (labels < nc)).sum()
+  assert abs(m.result() - O.mean_iou(want)) < 1e-12
+  for got, ref in zip(ev.confusion_matrix_to_iou_recall_precision(m.total_cm), O.iou_recall_precision(want)):
+    assert np.allclose(got, ref, rtol=0, atol=1e-12)
+  m.reset_state()
+  assert m.total_cm.sum() == 0
+
+
+def test_iou_known_answer(cuda):
+  # labels: 0 0 1 1 2 ; preds: 0 1 1 1 0  -> cm rows=labels
+  m = ev.MeanIoU(3)
+  m.update_state(np.array([0, 0, 1, 1, 2], np.int32), np.array([0, 1, 1, 1, 0], np.int32))
+  assert m.total_cm.tolist() == [[1, 1, 0], [0, 2, 0], [1, 0, 0]]
+  iou, recall, precision = ev.confusion_matrix_to_iou_recall_precision(m.total_cm)
+  assert np.allclose(iou, [1 / 3, 2 / 3, 0.0]) and np.allclose(recall, [0.5, 1.0, 0.0])
+  assert np.allclose(precision, [0.5, 2 / 3, 0.0])
+  assert abs(m.result() - (1 / 3 + 2 / 3 + 0.0) / 3) < 1e-12
+
+
+def test_evaluation_cli_on_real_scans(cuda, tmp_path, capsys):
+  g = np.load(os.path.join(GOLDEN, "model_ssv2_real_32x240.npz"))
+  d = tmp_path / "data" / "val"
+  d.mkdir(parents=True)
+  for i in range(2):
+    sample = np.concatenate([g["raw"][i], g["labels"][i][..., None].astype(np.float32)], -1)
+    np.save(str(d / ("s%d.npy" % i)), sample.astype(np.float64))
+  iou, recall, precision, miou = ev.main(["-d", str(tmp_path / "data"), "-i", "val", "-m", "squeezesegv2",
+                                          "-n", "squeezesegv2"])
+  out = capsys.readouterr().out
+  assert "ROAD" in out and "MIoU:" in out
+  labels = g["labels"].copy()
+  labels[~g["mask"]] = 10
+  decided = g["margin"] > 2e-3
+  assert decided.mean() > 0.99                       # the oracle's predictions define the expectation
+  want_cm = O.confusion_matrix(labels, g["preds"], 11)
+  got_miou = miou
+  assert abs(got_miou - O.mean_iou(want_cm)) < 0.02  # identical up to the few undecided pixels

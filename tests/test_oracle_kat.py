@@ -89,3 +89,17 @@ def test_leaky_relu_and_sigmoid():
   x = np.array([-2.0, 0.0, 3.0])
   assert O.leaky_relu(x).tolist() == [-0.2, 0.0, 3.0]
   assert np.allclose(O.sigmoid(np.array([0.0])), 0.5)
+
+
+def test_metrics_known_answer():
+  """reference: utils/util.py:64-79 with tf.metrics.MeanIoU's total_cm (rows = labels)."""
+  cm = O.confusion_matrix([0, 0, 1, 1, 2, 7, -1], [0, 1, 1, 1, 0, 0, 0], 3)   # 7 and -1 are ignored
+  assert cm.tolist() == [[1, 1, 0], [0, 2, 0], [1, 0, 0]]
+  iou, recall, precision = O.iou_recall_precision(cm)
+  assert np.allclose(iou, [1 / 3, 2 / 3, 0.0])
+  assert np.allclose(recall, [0.5, 1.0, 0.0])
+  assert np.allclose(precision, [0.5, 2 / 3, 0.0])
+  assert abs(O.mean_iou(cm) - 1 / 3) < 1e-12
+  assert O.mean_iou(np.zeros((3, 3))) == 0.0
+  absent = np.array([[4, 0, 0], [0, 0, 0], [0, 0, 2]])          # class 1 never occurs: not averaged
+  assert O.mean_iou(absent) == 1.0
