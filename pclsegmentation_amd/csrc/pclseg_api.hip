@@ -236,6 +236,17 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   a.inv_pw = ((1 << 20) + a.PW - 1) / a.PW;
   a.tilesH = (a.H + a.TH - 1) / a.TH;
   a.tilesW = (a.Wconv + a.SEGW * 16 - 1) / (a.SEGW * 16);
+  static const int use_direct = getenv("PCLSEG_DIRECT1X1") ? atoi(getenv("PCLSEG_DIRECT1X1")) : 1;
+  if (use_direct && !exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.cin_t % 8 == 0 &&
+      op.ck16 >= 32 && !a.skx && !a.res2 && op.sub[0].nctp <= 4) {  // squeeze-like: few couts
+    // LDS-free streaming GEMM; every wave owns mtw*16 pixels x ntw*16 couts
+    const int ntw = op.sub[0].nctp % 2 == 0 ? 2 : 1;
+    const int px_per_block = 4 * 2 * 16;
+    dim3 grid((unsigned)((a.Win + px_per_block - 1) / px_per_block), (unsigned)(op.sub[0].nctp / ntw));
+    if (ntw == 2) hipLaunchKernelGGL((conv1x1_direct_kernel<2, 2>), grid, dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_direct_kernel<2, 1>), grid, dim3(kConvThreads), 0, s, a);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)ny);

@@ -480,6 +480,123 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   }
 }
 
+// ---- 1x1 convolutions without LDS (split-f16 mode).
+// A 1x1 conv has no halo, so staging its input through LDS only buys the hi/lo split and costs two
+// block barriers per channel chunk plus the LDS footprint.  Here every wave is an independent
+// streaming GEMM: lane (p, g) loads the 8 channels {32t + 8g ..} of pixel p straight from
+// global memory (4 lanes cover 128 contiguous bytes of a pixel), splits them to f16 hi/lo in
+// registers and feeds the MFMAs; the operands of K-step t+1 are in flight while step t computes.
+// No barriers, no LDS -> occupancy is bounded by registers only.  Uses the same packed weight
+// fragments as conv_kernel (K-step t of the packed array covers channel groups 4t .. 4t+3 when
+// the packing chunk is 32 or 64 channels).  Requires Cin % 8 == 0.
+template <int MTW, int NTW>
+__global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const ConvArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const ConvSub& S = a.sub[0];
+  const int total = a.Win;  // flattened pixel count (N = H = 1 view)
+  const int pix0 = ((int)blockIdx.x * 4 + wave) * (MTW * 16);
+  if (pix0 >= total) return;
+  const int ct0 = blockIdx.y * NTW;
+  const int cin8 = a.Cin >> 3;
+  const int nsteps = (cin8 + 3) >> 2;
+
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* xptr[MTW];
+  bool pvalid[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int px = pix0 + m * 16 + p;
+    pvalid[m] = px < total;
+    xptr[m] = a.in + (size_t)(pvalid[m] ? px : 0) * a.Cin + g * 8;
+  }
+  const _Float16* wbase = S.w16 + (size_t)ct0 * 1024 + lane * 8;
+
+  f32x4 xa[MTW], xb[MTW];       // raw float32 operands of the step being prefetched
+  f16x8 wh[NTW], wl[NTW];
+  auto load_step = [&](int t) {
+    const bool gok = (4 * t + g) < cin8;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const float* src = (gok && pvalid[m]) ? xptr[m] + t * 32 : a.in;
+      xa[m] = *reinterpret_cast<const f32x4*>(src);
+      xb[m] = *reinterpret_cast<const f32x4*>(src + 4);
+      if (!(gok && pvalid[m])) { xa[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; xb[m] = xa[m]; }
+    }
+    const _Float16* wp = wbase + (size_t)t * S.nctp * 1024;
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn) {
+      wh[nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+      wl[nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+    }
+  };
+
+  load_step(0);
+  for (int t = 0; t < nsteps; ++t) {
+    // split this step's activations, keep its weights, then refill the raw registers
+    f16x8 xh[MTW], xl[MTW], ch[NTW], cl[NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const _Float16 h0 = (_Float16)xa[m][e];
+        const _Float16 h1 = (_Float16)xb[m][e];
+        xh[m][e] = h0;
+        xh[m][4 + e] = h1;
+        xl[m][e] = (_Float16)(xa[m][e] - (float)h0);
+        xl[m][4 + e] = (_Float16)(xb[m][e] - (float)h1);
+      }
+    }
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn) { ch[nn] = wh[nn]; cl[nn] = wl[nn]; }
+    if (t + 1 < nsteps) load_step(t + 1);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NTW; ++nn) {
+        acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[nn], xh[m], acc[m][nn], 0, 0, 0);
+        acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[nn], xl[m], acc[m][nn], 0, 0, 0);
+        acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[nn], xh[m], acc[m][nn], 0, 0, 0);
+      }
+  }
+
+  // epilogue (two passes: residual operands first, then the stores; see conv_kernel)
+  f32x4 r1[MTW][NTW];
+  if (a.res1) {
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NTW; ++nn) {
+        const int co = (ct0 + nn) * 16 + g * 4;
+        const bool ok = pvalid[m] && co < S.Cout;
+        r1[m][nn] = *reinterpret_cast<const f32x4*>(
+            ok ? a.res1 + (size_t)(pix0 + m * 16 + p) * a.res1_C + S.co_off + co : a.res1);
+      }
+  }
+#pragma unroll
+  for (int nn = 0; nn < NTW; ++nn) {
+    const int co = (ct0 + nn) * 16 + g * 4;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(S.bias + co);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      if (pvalid[m] && co < S.Cout) {
+        f32x4 v = acc[m][nn] + bv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
+        if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
+        *reinterpret_cast<f32x4*>(a.out + (size_t)(pix0 + m * 16 + p) * a.out_C + S.co_off + co) = v;
+      }
+    }
+  }
+}
+
 // ---- Context Aggregation Module, one kernel (reference: nets/SqueezeSegV2.py:30-70)
 //   out = x * sigmoid(BN(W2 . relu(BN(W1 . maxpool7x7_s1_SAME(x)))))          C -> C/16 -> C
 // A block owns an 8x32 pixel tile.  Channels are swept in chunks of kCamCK: the (8+6)x(32+6) halo
