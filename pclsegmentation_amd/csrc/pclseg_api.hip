@@ -240,11 +240,22 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   if (use_direct && !exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.cin_t % 8 == 0 &&
       op.ck16 >= 32 && !a.skx && !a.res2 && op.sub[0].nctp <= 4) {  // squeeze-like: few couts
     // LDS-free streaming GEMM; every wave owns mtw*16 pixels x ntw*16 couts
-    const int ntw = op.sub[0].nctp % 2 == 0 ? 2 : 1;
-    const int px_per_block = 4 * 2 * 16;
-    dim3 grid((unsigned)((a.Win + px_per_block - 1) / px_per_block), (unsigned)(op.sub[0].nctp / ntw));
-    if (ntw == 2) hipLaunchKernelGGL((conv1x1_direct_kernel<2, 2>), grid, dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv1x1_direct_kernel<2, 1>), grid, dim3(kConvThreads), 0, s, a);
+    // one block column covers ALL couts (nctp <= 4 tiles), so the input is read exactly once
+    const int ntw = op.sub[0].nctp;
+    const int mtw = ntw == 4 ? 1 : 2;  // 4 cout tiles x 2 segments would spill at 128 VGPRs
+    const int px_per_block = 4 * mtw * 16;
+    dim3 grid((unsigned)((a.Win + px_per_block - 1) / px_per_block), 1u);
+    const bool res = a.res1 != nullptr;
+#define PCLSEG_D(MTW_, NTW_) \
+    do { if (res) hipLaunchKernelGGL((conv1x1_direct_kernel<MTW_, NTW_, true>), grid, dim3(kConvThreads), 0, s, a); \
+         else hipLaunchKernelGGL((conv1x1_direct_kernel<MTW_, NTW_, false>), grid, dim3(kConvThreads), 0, s, a); } while (0)
+    switch (ntw) {
+      case 1: PCLSEG_D(2, 1); break;
+      case 2: PCLSEG_D(2, 2); break;
+      case 3: PCLSEG_D(2, 3); break;
+      default: PCLSEG_D(1, 4); break;
+    }
+#undef PCLSEG_D
     return hipGetLastError();
   }
   const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
 // No barriers, no LDS -> occupancy is bounded by registers only.  Uses the same packed weight
 // fragments as conv_kernel (K-step t of the packed array covers channel groups 4t .. 4t+3 when
 // the packing chunk is 32 or 64 channels).  Requires Cin % 8 == 0.
-template <int MTW, int NTW>
+template <int MTW, int NTW, bool RES>
 __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const C
   }
 
   // epilogue (two passes: residual operands first, then the stores; see conv_kernel)
-  f32x4 r1[MTW][NTW];
-  if (a.res1) {
+  f32x4 r1[RES ? MTW : 1][NTW];
+  if constexpr (RES) if (a.res1) {
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const C
         f32x4 v = acc[m][nn] + bv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
-        if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
+        if constexpr (RES) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
         *reinterpret_cast<f32x4*>(a.out + (size_t)(pix0 + m * 16 + p) * a.out_C + S.co_off + co) = v;
       }
     }
