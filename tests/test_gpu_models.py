@@ -161,3 +161,43 @@ def test_inference_cli_writes_reference_outputs(cuda, tmp_path):
       assert img.mode == "RGBA" and img.size == (240, 32)
     rgb = np.asarray(Image.open(str(out / ("plot_scan%d.png" % i))))[..., :3]
     assert np.array_equal(rgb, (255 * np.asarray(mc.CLS_COLOR_MAP)[pred]).astype(np.uint8))
+
+
+def test_full_size_kitti_shape(cuda):
+  """BASELINE configs[1] at its real size (SqueezeSegV2, 64x2048, 20 classes, batch 32):
+  one scan against the float64 oracle, and size-independent properties over the whole batch —
+  every scan's result is independent of the batch it travels in (micro-batch / lane placement),
+  masked pixels carry the None class, and a repeat run is bit-identical."""
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2kitti", height=64, width=2048)
+  model.init_weights(4321)
+  raw = synthetic_scans(32, 64, 2048, mc.INPUT_MEAN, mc.INPUT_STD, 0.78, seed=1234)
+  preds, logits, mask, _ = run_engine(model, raw)
+  assert (preds[~mask] == 0).all() and preds.min() >= 0 and preds.max() < 20
+  # (a) oracle on scan 7 alone
+  lidar, omask = O.normalize_and_mask(raw[7:8], mc.INPUT_MEAN, mc.INPUT_STD)
+  _, opred, ologits = O.forward("squeezesegv2", model.weights, lidar, omask, 0, dtype=np.float64)
+  assert np.array_equal(omask[0], mask[7])
+  srt = np.sort(ologits[0], -1)
+  check_against(preds[7], logits[7], mask[7], ologits[0], opred[0], (srt[..., -1] - srt[..., -2]), 0)
+  # (b) batch-composition invariance: scans 7, 19, 31 alone == inside the batch of 32
+  for i in (7, 19, 31):
+    p1, l1, _, _ = run_engine(model, raw[i:i + 1])
+    assert np.array_equal(p1[0], preds[i]) and np.array_equal(l1[0], logits[i])
+  # (c) determinism of the multi-lane schedule
+  p2, l2, _, _ = run_engine(model, raw)
+  assert np.array_equal(p2, preds) and np.array_equal(l2, logits)
+
+
+def test_full_size_darknet21_nuscenes_shape(cuda):
+  """BASELINE configs[4]: Darknet-21 at 32x1024 — one scan against the oracle plus batch
+  invariance."""
+  mc, model = P.load_model_config("darknet21", "darknet21", height=32, width=1024)
+  model.init_weights(4321)
+  raw = synthetic_scans(5, 32, 1024, mc.INPUT_MEAN, mc.INPUT_STD, 0.59, seed=1234)
+  preds, logits, mask, _ = run_engine(model, raw)
+  lidar, omask = O.normalize_and_mask(raw[2:3], mc.INPUT_MEAN, mc.INPUT_STD)
+  _, opred, ologits = O.forward("darknet21", model.weights, lidar, omask, 10, num_layers=21, dtype=np.float64)
+  srt = np.sort(ologits[0], -1)
+  check_against(preds[2], logits[2], mask[2], ologits[0], opred[0], (srt[..., -1] - srt[..., -2]), 10)
+  p1, l1, _, _ = run_engine(model, raw[2:3])
+  assert np.array_equal(p1[0], preds[2]) and np.array_equal(l1[0], logits[2])
