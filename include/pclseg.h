@@ -203,6 +203,19 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
 int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size_t count,
                                int num_class, int64_t* cm, void* hip_stream);
 
+/* Spherical projection, the step before the network (dataset_convert/laserscan_semantic_kitti.py:
+ * 106-166, LaserScan.do_range_projection; used by dataset_convert/semantic_kitti.py:150-179).
+ *   points   float32 [m,4]   x, y, z, remission                          (device)
+ *   image5   float32 [H,W,5] x, y, z, remission, depth of the NEAREST point of each pixel;
+ *                            pixels without a point hold `empty` (-1 like LaserScan's attributes,
+ *                            0 like the .npy files the converter writes)     (device, out)
+ *   proj_idx int32   [H,W]   index of the winning point, -1 = none          (device, out, optional)
+ *   scratch  uint64  [H*W]   work space                                     (device)
+ * fov_up / fov_down in degrees.  Asynchronous on `hip_stream`. */
+int pclseg_op_project(const float* points, size_t m, int h, int w, float fov_up, float fov_down,
+                      float empty, float* image5, int32_t* proj_idx, uint64_t* scratch,
+                      void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

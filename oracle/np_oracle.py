@@ -352,3 +352,38 @@ def mean_iou(cm):
   denom = cm.sum(axis=0) + cm.sum(axis=1) - tp
   valid = denom != 0
   return float((_divide_no_nan(tp, denom)).sum() / valid.sum()) if valid.any() else 0.0
+
+
+# --------------------------------------------------------------------------- spherical projection
+def range_projection(points, H, W, fov_up, fov_down):
+  """Point cloud [M,4] (x,y,z,remission, float32) -> range image, restating
+  dataset_convert/laserscan_semantic_kitti.py:106-166 (LaserScan.do_range_projection) with the
+  same float32 NumPy operations in the same order.  Pinned by tests/golden/projection_*.npz,
+  which are outputs of the reference's own code (tests/golden/make_projection_golden.py).
+  Returns (proj_range [H,W], proj_xyz [H,W,3], proj_remission [H,W], proj_idx [H,W] int32);
+  -1 marks pixels without a point; the nearest point wins a pixel."""
+  points = np.asarray(points, np.float32)
+  xyz, rem = points[:, :3], points[:, 3]
+  fov_up_r = fov_up / 180.0 * np.pi
+  fov_down_r = fov_down / 180.0 * np.pi
+  fov = abs(fov_down_r) + abs(fov_up_r)
+  depth = np.linalg.norm(xyz, 2, axis=1)
+  yaw = -np.arctan2(xyz[:, 1], xyz[:, 0])
+  pitch = np.arcsin(xyz[:, 2] / depth)
+  proj_x = 0.5 * (yaw / np.pi + 1.0)
+  proj_y = 1.0 - (pitch + abs(fov_down_r)) / fov
+  proj_x *= W
+  proj_y *= H
+  proj_x = np.maximum(0, np.minimum(W - 1, np.floor(proj_x))).astype(np.int32)
+  proj_y = np.maximum(0, np.minimum(H - 1, np.floor(proj_y))).astype(np.int32)
+  order = np.argsort(depth)[::-1]          # decreasing depth: the nearest point is written last
+  proj_range = np.full((H, W), -1, np.float32)
+  proj_xyz = np.full((H, W, 3), -1, np.float32)
+  proj_rem = np.full((H, W), -1, np.float32)
+  proj_idx = np.full((H, W), -1, np.int32)
+  py, px = proj_y[order], proj_x[order]
+  proj_range[py, px] = depth[order]
+  proj_xyz[py, px] = xyz[order]
+  proj_rem[py, px] = rem[order]
+  proj_idx[py, px] = np.arange(depth.shape[0])[order]
+  return proj_range, proj_xyz, proj_rem, proj_idx

@@ -1,6 +1,7 @@
 // pclseg_api.hip — the engine behind include/pclseg.h: weight folding/packing, workspace,
 // kernel sequencing on one HIP stream, and the C ABI.  gfx950 only; there is no CPU path.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -876,6 +877,28 @@ int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size
   hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(256), (size_t)num_class * num_class * sizeof(unsigned int),
                      (hipStream_t)hip_stream, labels, preds, count, num_class,
                      reinterpret_cast<unsigned long long*>(cm));
+  HIP_TRY(nullptr, hipGetLastError());
+  return PCLSEG_OK;
+}
+
+int pclseg_op_project(const float* points, size_t m, int h, int w, float fov_up, float fov_down,
+                      float empty, float* image5, int32_t* proj_idx, uint64_t* scratch,
+                      void* hip_stream) {
+  if (!points || !image5 || !scratch || h <= 0 || w <= 0 || m > 0x7fffffffull)
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_project");
+  const double up = (double)fov_up / 180.0 * M_PI, down = (double)fov_down / 180.0 * M_PI;
+  const double fov = std::fabs(down) + std::fabs(up);
+  if (!(fov > 0.0)) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "field of view must be positive");
+  ProjArgs pa;
+  pa.H = h; pa.W = w;
+  pa.fpi = (float)M_PI; pa.fdown = (float)std::fabs(down); pa.ffov = (float)fov;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int npix = h * w;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(scratch);
+  hipLaunchKernelGGL(proj_init_kernel, dim3(stream_blocks((size_t)npix)), dim3(256), 0, s, keys, npix);
+  if (m) hipLaunchKernelGGL(proj_scatter_kernel, dim3(stream_blocks(m)), dim3(256), 0, s, points, m, keys, pa);
+  hipLaunchKernelGGL(proj_gather_kernel, dim3(stream_blocks((size_t)npix)), dim3(256), 0, s, points, keys,
+                     npix, empty, image5, proj_idx);
   HIP_TRY(nullptr, hipGetLastError());
   return PCLSEG_OK;
 }

@@ -873,4 +873,66 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restric
   }
 }
 
+// ---- spherical projection: point cloud -> range image (the step before the network;
+// reference: dataset_convert/laserscan_semantic_kitti.py:106-166, LaserScan.do_range_projection).
+// The reference sorts the points by decreasing depth and scatters them, so the NEAREST point
+// wins a pixel.  Here: one 64-bit atomicMin per point on key = (depth bits << 32) | point index
+// (positive floats order like their bit patterns; equal depths -> lowest index), then one gather
+// per pixel.  The float32 arithmetic follows NumPy's operation order with contraction disabled;
+// atan2 / asin are evaluated in float64 and rounded once.  Points at the origin are skipped.
+struct ProjArgs {
+  int H, W;
+  float fpi, fdown, ffov;  // float32(pi), float32(|fov_down| rad), float32(fov rad)
+};
+
+__global__ __launch_bounds__(256) void proj_init_kernel(unsigned long long* __restrict__ keys, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void proj_scatter_kernel(const float* __restrict__ pts, size_t m,
+                                                           unsigned long long* __restrict__ keys,
+                                                           const ProjArgs a) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 pt = *reinterpret_cast<const f32x4*>(pts + i * 4);
+    const float x = pt[0], y = pt[1], z = pt[2];
+    float depth, px, py;
+    {
+#pragma clang fp contract(off)   // NumPy does not fuse multiply-add: keep every rounding
+      const float d2 = (x * x + y * y) + z * z;
+      depth = sqrtf(d2);
+      if (!(depth > 0.0f)) continue;
+      const float yaw = -(float)atan2((double)y, (double)x);
+      const float pitch = (float)asin((double)(z / depth));
+      px = 0.5f * (yaw / a.fpi + 1.0f);
+      py = 1.0f - (pitch + a.fdown) / a.ffov;
+      px = floorf(px * (float)a.W);
+      py = floorf(py * (float)a.H);
+    }
+    const int ix = (int)fmaxf(0.0f, fminf((float)(a.W - 1), px));
+    const int iy = (int)fmaxf(0.0f, fminf((float)(a.H - 1), py));
+    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)i;
+    atomicMin(&keys[(size_t)iy * a.W + ix], key);
+  }
+}
+
+__global__ __launch_bounds__(256) void proj_gather_kernel(const float* __restrict__ pts,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          int npix, float empty, float* __restrict__ image5,
+                                                          int32_t* __restrict__ proj_idx) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+    const unsigned long long key = keys[i];
+    float o[5] = {empty, empty, empty, empty, empty};
+    int idx = -1;
+    if (key != ~0ull) {
+      idx = (int)(unsigned)(key & 0xffffffffull);
+      const f32x4 pt = *reinterpret_cast<const f32x4*>(pts + (size_t)idx * 4);
+      o[0] = pt[0]; o[1] = pt[1]; o[2] = pt[2]; o[3] = pt[3];
+      o[4] = __uint_as_float((unsigned)(key >> 32));
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) image5[(size_t)i * 5 + c] = o[c];
+    if (proj_idx) proj_idx[i] = idx;
+  }
+}
+
 }  // namespace pclseg

@@ -33,7 +33,7 @@ EXPORTS = [
   "pclseg_set_stream", "pclseg_sync", "pclseg_forward", "pclseg_forward_raw",
   "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
   "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
-  "pclseg_op_confusion_matrix",
+  "pclseg_op_confusion_matrix", "pclseg_op_project",
 ]
 
 
@@ -95,6 +95,8 @@ def load_library():
   lib.pclseg_op_max_pool.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp]
   lib.pclseg_op_head.argtypes = [vp, vp, i32, i32, i32, i32, f32p, f32p, i32, i32, vp, vp, vp, i32]
   lib.pclseg_op_confusion_matrix.argtypes = [vp, vp, ctypes.c_size_t, i32, vp, vp]
+  lib.pclseg_op_project.argtypes = [vp, ctypes.c_size_t, i32, i32, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, vp, vp, vp, vp]
   for name in EXPORTS:
     fn = getattr(lib, name)
     if name not in ("pclseg_last_error",):
@@ -296,3 +298,10 @@ def op_confusion_matrix(labels_dev, preds_dev, count, num_class, cm_dev, stream=
   """cm[label][pred] += 1 (device int64 [NC,NC], accumulating)."""
   check(load_library().pclseg_op_confusion_matrix(_ptr(labels_dev), _ptr(preds_dev), int(count),
                                                   int(num_class), _ptr(cm_dev), ctypes.c_void_p(stream or 0)))
+
+
+def op_project(points_dev, m, h, w, fov_up, fov_down, empty, image5_dev, proj_idx_dev, scratch_dev, stream=0):
+  """Spherical projection of [m,4] points into an [h,w,5] range image (nearest point wins)."""
+  check(load_library().pclseg_op_project(_ptr(points_dev), int(m), int(h), int(w), float(fov_up),
+                                         float(fov_down), float(empty), _ptr(image5_dev),
+                                         _ptr(proj_idx_dev), _ptr(scratch_dev), ctypes.c_void_p(stream or 0)))

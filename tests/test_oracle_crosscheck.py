@@ -73,3 +73,15 @@ def test_darknet_output_stride_variants():
   assert O.darknet_strides(16) == ([2, 2, 2, 2, 1], [1, 2, 2, 2, 2])
   assert O.darknet_strides(32) == ([2, 2, 2, 2, 2], [2, 2, 2, 2, 2])
   assert O.darknet_strides(8) == ([2, 2, 2, 1, 1], [1, 1, 2, 2, 2])
+
+
+@pytest.mark.parametrize("name", ["kitti_64x1024", "small_32x256", "nuscenes_like_32x1024"])
+def test_projection_oracle_reproduces_reference_outputs(name):
+  """The projection restatement against outputs of the REFERENCE's own NumPy code
+  (dataset_convert/laserscan_semantic_kitti.py, vectors made by make_projection_golden.py)."""
+  g = np.load(os.path.join(GOLDEN, "projection_%s.npz" % name))
+  rng_, xyz, rem, idx = O.range_projection(g["points"], int(g["H"]), int(g["W"]), float(g["fov_up"]),
+                                           float(g["fov_down"]))
+  assert np.array_equal(idx, g["proj_idx"])
+  assert np.array_equal(rng_, g["proj_range"]) and np.array_equal(xyz, g["proj_xyz"])
+  assert np.array_equal(rem, g["proj_remission"])
