@@ -616,7 +616,7 @@ struct CamArgs {
 };
 
 constexpr int kCamTH = 8, kCamTW = 32, kCamPH = kCamTH + 6, kCamPW = kCamTW + 6;
-constexpr int kCamCK = 8;  // channels per chunk: 31 KiB of LDS per block -> 5 blocks per CU
+constexpr int kCamCK = 16;  // channels per chunk = one 64-byte HBM granule per pixel (8 would halve the LDS but doubles the fetched bytes)
 constexpr int kCamPatchFloats = kCamPH * kCamPW * kCamCK;
 constexpr int kCamTmpFloats = kCamPH * kCamTW * kCamCK;
 
