@@ -12,12 +12,15 @@ Differences, all deliberate:
     ``--config`` selects the config (default: the model file's own, else the model's namesake);
   * scans are batched (``--batch``) and normalise+mask runs on the device inside
     ``pclseg_forward_raw`` instead of per-scan NumPy on the host;
+  * the per-scan outputs (one .npy and two PNG encodes, which dominate the reference's wall
+    time, SURVEY.md §3.1) are written by a small thread pool while the GPU runs the next batch;
   * ``<name>`` is the file's base name without extension (the reference's
     ``f.strip('.npy')`` strips characters, not the suffix);
   * ``-p`` takes this engine's ``.npz`` model file (``model.save``); without ``-p`` the model
     gets the seeded synthetic weights and says so.
 """
 import argparse
+import concurrent.futures
 import glob
 import os
 import sys
@@ -60,6 +63,24 @@ def inference(arg):
     batches = tqdm.tqdm(range(0, len(files), arg.batch))
   except ImportError:
     batches = range(0, len(files), arg.batch)
+  pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, arg.writers))
+  pending = []
+
+  def write_one(f, sample, pred, m):
+    name = os.path.splitext(os.path.basename(f))[0]
+    np.save(os.path.join(arg.output_dir, "pred_" + name + ".npy"), pred)
+    if arg.no_plots:
+      return
+    if sample.shape[2] > 5:
+      label = sample[:, :, 5].astype(np.int32)
+      label[~m] = none_index                      # reference: inference.py:65-68
+    else:
+      label = np.full(pred.shape, none_index, np.int32)
+    # the reference plots channel 3 of the NORMALISED lidar tensor (inference.py:88)
+    feat = (sample[:, :, 3].astype(np.float64) - config.INPUT_MEAN.ravel()[3]) / config.INPUT_STD.ravel()[3]
+    feat[~m] = 0.0
+    _save_plots(arg.output_dir, name, config, pred, label, feat)
+
   for b0 in batches:
     chunk = files[b0:b0 + arg.batch]
     samples = [np.load(f).astype(np.float32, copy=False) for f in chunk]
@@ -71,19 +92,10 @@ def inference(arg):
     predictions = predictions.numpy()
     for f, sample, pred, m in zip(chunk, samples, predictions, mask):
       print("Process: {0}".format(f))
-      name = os.path.splitext(os.path.basename(f))[0]
-      np.save(os.path.join(arg.output_dir, "pred_" + name + ".npy"), pred)
-      if arg.no_plots:
-        continue
-      if sample.shape[2] > 5:
-        label = sample[:, :, 5].astype(np.int32)
-        label[~m] = none_index                      # reference: inference.py:65-68
-      else:
-        label = np.full(pred.shape, none_index, np.int32)
-      # the reference plots channel 3 of the NORMALISED lidar tensor (inference.py:88)
-      feat = (sample[:, :, 3].astype(np.float64) - config.INPUT_MEAN.ravel()[3]) / config.INPUT_STD.ravel()[3]
-      feat[~m] = 0.0
-      _save_plots(arg.output_dir, name, config, pred, label, feat)
+      pending.append(pool.submit(write_one, f, sample, np.array(pred), np.array(m)))
+  for fut in pending:
+    fut.result()          # surface any writer exception
+  pool.shutdown()
 
 
 def main(argv=None):
@@ -100,6 +112,7 @@ def main(argv=None):
                       help="Config name (config_map key); default: the model's namesake")
   parser.add_argument("--batch", type=int, default=32, help="scans per forward call")
   parser.add_argument("--no_plots", action="store_true", help="write only pred_*.npy")
+  parser.add_argument("--writers", type=int, default=4, help="output writer threads")
   inference(parser.parse_args(argv))
 
 
