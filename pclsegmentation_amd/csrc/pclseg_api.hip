@@ -220,6 +220,7 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
     d.act = su.act;
     ny += d.ny;
   }
+  a.ny = ny;
   int wo, pl, ho, pt;
   same_pad(Win, op.pkw, op.sw, &wo, &pl);
   same_pad(H, op.pkh, 1, &ho, &pt);
@@ -261,7 +262,7 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   }
   const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW), (unsigned)ny);
+  dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
   if (op.kind == OP_HEAD)
     return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
@@ -272,14 +273,14 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
 
 hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {
   c.N = N; c.H = H; c.W = W;
-  c.tilesH = (H + kCamTH - 1) / kCamTH;
+  constexpr int kTH = 4, kCK = 64;  // 4 x 26 pixel tiles, 64-channel chunks, 512-thread blocks
+  const int R = C / 16;
+  c.tilesH = (H + kTH - 1) / kTH;
   c.tilesW = (W + kCamTW - 1) / kCamTW;
   const dim3 grid((unsigned)(N * c.tilesH * c.tilesW));
-  // chunk buffers, then (aliased after the chunk loop) s[256][R] + w2[R][C]
-  const int R = C / 16;
-  const size_t lds = (size_t)std::max(kCamPatchFloats + kCamTmpFloats + kCamCK * R, 256 * R + R * C) * sizeof(float);
-  if (C == 64) hipLaunchKernelGGL((cam_kernel<64, 4>), grid, dim3(256), lds, s, c);
-  else if (C == 128) hipLaunchKernelGGL((cam_kernel<128, 8>), grid, dim3(256), lds, s, c);
+  const size_t lds = (size_t)(kTH * kCamPW * kCK + kCK * R) * sizeof(float);
+  if (C == 64) hipLaunchKernelGGL((cam_kernel<64, 4, kTH, kCK>), grid, dim3(8 * kCK), lds, s, c);
+  else if (C == 128) hipLaunchKernelGGL((cam_kernel<128, 8, kTH, kCK>), grid, dim3(8 * kCK), lds, s, c);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -289,6 +290,14 @@ hipError_t launch_pool(const float* in, float* out, int N, int H, int Win, int C
   int wo, pl, ho, pt;
   same_pad(Win, kw, sw, &wo, &pl);
   same_pad(H, kh, 1, &ho, &pt);
+  if (kh == 3 && kw == 3 && sw == 2) {
+    constexpr int kRows = 4;
+    const size_t items = (size_t)N * ((H + kRows - 1) / kRows) * wo * (C / 4);
+    if (items > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((maxpool3x3s2_kernel<kRows>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+                       in, out, N, H, Win, wo, C, pl);
+    return hipGetLastError();
+  }
   const size_t total = (size_t)N * H * wo * (C / 4);
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, in, out, N, H, Win, wo, C, kh, kw,

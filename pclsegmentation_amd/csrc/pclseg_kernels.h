@@ -72,8 +72,18 @@ struct ConvArgs {
   int CK;      // channels staged per LDS pass (f16x3: 64/32/16, exact: 32/16)
   int inv_pw;  // ceil(2^20 / PW): pixel index -> patch row by multiply-shift
   int nsub;
+  int ny;      // blocks per pixel tile (all sub-convs' cout groups)
   ConvSub sub[2];
 };
+
+// Blocks are dealt round-robin over the 8 XCDs (private L2 each).  Remap the linear block id so
+// every XCD works on one CONTIGUOUS range of logical ids: neighbouring tiles (shared halo) and the
+// cout groups of one tile (same input patch) then run back to back on the same L2.  Bijective
+// for any grid size; a pure speed choice, results never depend on it.
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -100,14 +110,16 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   const int p = lane & 15;  // pixel within the 16-pixel segment
   const int g = lane >> 4;  // k-group (operands) / cout quad (accumulator)
 
-  int tile = blockIdx.x;
+  // logical id = tile * ny + cout group: the groups of one tile are neighbours on one XCD
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = lid / a.ny;
+  const int by = lid - tile * a.ny;
   const int twi = tile % a.tilesW;
   tile /= a.tilesW;
   const int thi = tile % a.tilesH;
   const int n = tile / a.tilesH;
   const int h0 = thi * a.TH;
   const int w0 = twi * (a.SEGW * 16);
-  const int by = blockIdx.y;
   const int si = (a.nsub > 1 && by >= a.sub[0].ny) ? 1 : 0;
   const ConvSub& S = a.sub[si];
   const int ct0 = (by - (si ? a.sub[0].ny : 0)) * (NTW * WN) + wn * NTW;
@@ -597,182 +609,8 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const C
   }
 }
 
-// ---- Context Aggregation Module, one kernel (reference: nets/SqueezeSegV2.py:30-70)
-//   out = x * sigmoid(BN(W2 . relu(BN(W1 . maxpool7x7_s1_SAME(x)))))          C -> C/16 -> C
-// A block owns an 8x32 pixel tile.  Channels are swept in chunks of kCamCK: the (8+6)x(32+6) halo
-// patch goes to LDS (-inf outside the image: padding never wins), the 7x7 max is taken separably
-// (row pass LDS->LDS, column pass LDS->registers) and each thread folds its pooled channel quad
-// into partial squeeze sums.  The next chunk's global loads are in flight during both passes.
-// The gate is then applied in a second, fully coalesced sweep over the tile's own pixels.
-// Everything is float32 on the VALU (the two 1x1 convs are 2*C*C/16 MACs per pixel).
-struct CamArgs {
-  const float* x;   // [N,H,W,C]
-  float* out;       // [N,H,W,C]
-  const float* w1;  // [C][R]  BN-folded squeeze weights
-  const float* b1;  // [R]
-  const float* w2;  // [R][C]  BN-folded excitation weights
-  const float* b2;  // [C]
-  int N, H, W, tilesH, tilesW;
-};
-
-constexpr int kCamTH = 8, kCamTW = 32, kCamPH = kCamTH + 6, kCamPW = kCamTW + 6;
-constexpr int kCamCK = 16;  // channels per chunk = one 64-byte HBM granule per pixel (8 would halve the LDS but doubles the fetched bytes)
-constexpr int kCamPatchFloats = kCamPH * kCamPW * kCamCK;
-constexpr int kCamTmpFloats = kCamPH * kCamTW * kCamCK;
-
-template <int C, int R>
-__global__ __launch_bounds__(256) void cam_kernel(const CamArgs a) {
-  constexpr int CK = kCamCK;
-  constexpr int QP = CK / 4;                 // channel quads per pixel in a chunk (2)
-  constexpr int LQ = QP == 4 ? 2 : 1;        // log2(QP)
-  constexpr int PPR = 256 / QP;              // pixels covered per staging / column round
-  constexpr int NPIX = kCamPH * kCamPW;      // 532 patch pixels
-  constexpr int NSTAGE = (NPIX + PPR - 1) / PPR;
-  constexpr int NROW = kCamPH * kCamTW * QP; // row-pass items
-  constexpr int NCOL = (kCamTH * kCamTW) / PPR;  // column-pass rounds per thread
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* patch = reinterpret_cast<float*>(smem_raw);
-  float* tmp = patch + kCamPatchFloats;
-  float* w1c = tmp + kCamTmpFloats;  // [CK][R]
-  const int tid = threadIdx.x;
-  int tile = blockIdx.x;
-  const int twi = tile % a.tilesW;
-  tile /= a.tilesW;
-  const int thi = tile % a.tilesH;
-  const int n = tile / a.tilesH;
-  const int h0 = thi * kCamTH, w0 = twi * kCamTW;
-  const float* xn = a.x + (size_t)n * a.H * a.W * C;
-  const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-
-  // staging assignment: item = (patch pixel, channel quad), quad fastest
-  const int sq = tid & (QP - 1);
-  auto stage_load = [&](int chunk, f32x4 (&v)[NSTAGE]) {
-#pragma unroll
-    for (int k = 0; k < NSTAGE; ++k) {
-      const int pix = (tid >> LQ) + k * PPR;
-      const int pr = pix / kCamPW, pc = pix - pr * kCamPW;
-      const int h = h0 - 3 + pr, w = w0 - 3 + pc;
-      const bool ok = pix < NPIX && h >= 0 && h < a.H && w >= 0 && w < a.W;
-      const float* src = ok ? xn + ((size_t)h * a.W + w) * C + chunk * CK + sq * 4 : xn;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-      v[k] = ok ? t : ninf;
-    }
-  };
-
-  // squeeze partial sums: this thread owns channel quad `sq` of pixels (tid>>LQ) + PPR*it
-  float sp[NCOL][R];
-#pragma unroll
-  for (int it = 0; it < NCOL; ++it)
-#pragma unroll
-    for (int r = 0; r < R; ++r) sp[it][r] = 0.f;
-
-  f32x4 v[NSTAGE];
-  stage_load(0, v);
-  constexpr int NCH = C / CK;
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-#pragma unroll
-    for (int k = 0; k < NSTAGE; ++k) {
-      const int pix = (tid >> LQ) + k * PPR;
-      if (pix < NPIX) *reinterpret_cast<f32x4*>(patch + pix * CK + sq * 4) = v[k];
-    }
-    if (tid < CK * R / 4)  // this chunk's squeeze weights: rows chunk*CK .. of [C][R]
-      *reinterpret_cast<f32x4*>(w1c + tid * 4) =
-          *reinterpret_cast<const f32x4*>(a.w1 + (size_t)chunk * CK * R + tid * 4);
-    __syncthreads();
-    if (chunk + 1 < NCH) stage_load(chunk + 1, v);
-    // row pass: tmp[pr][tc][q] = max_j patch[pr][tc + j][q]
-#pragma unroll
-    for (int it = 0; it < (NROW + 255) / 256; ++it) {
-      const int idx = it * 256 + tid;
-      if (idx < NROW) {
-        const int q = idx & (QP - 1), tc = (idx >> LQ) & 31, pr = idx >> (LQ + 5);
-        const float* src = patch + (pr * kCamPW + tc) * CK + q * 4;
-        f32x4 m = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-        for (int j = 1; j < 7; ++j) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(src + j * CK);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
-        }
-        *reinterpret_cast<f32x4*>(tmp + (pr * kCamTW + tc) * CK + q * 4) = m;
-      }
-    }
-    __syncthreads();
-    // column pass + squeeze partial sums
-#pragma unroll
-    for (int it = 0; it < NCOL; ++it) {
-      const int px = (tid >> LQ) + it * PPR;
-      const int tr = px >> 5, tc = px & 31;
-      const float* src = tmp + (tr * kCamTW + tc) * CK + sq * 4;
-      f32x4 m = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-      for (int i = 1; i < 7; ++i) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + i * kCamTW * CK);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* wr = w1c + (sq * 4 + e) * R;
-#pragma unroll
-        for (int r = 0; r < R; ++r) sp[it][r] = fmaf(m[e], wr[r], sp[it][r]);
-      }
-    }
-    __syncthreads();
-  }
-
-  // finish the squeeze: sum the QP quad-lanes of each pixel, + bias, ReLU -> LDS s[256][R]
-  float* s_lds = patch;             // [256][R]
-  float* w2_lds = patch + 256 * R;  // [R][C]
-#pragma unroll
-  for (int it = 0; it < NCOL; ++it) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float t = sp[it][r];
-      t += __shfl_xor(t, 1);
-      if (QP == 4) t += __shfl_xor(t, 2);
-      sp[it][r] = fmaxf(t + a.b1[r], 0.f);
-    }
-    if (sq == 0) {
-      const int px = (tid >> LQ) + it * PPR;
-#pragma unroll
-      for (int r = 0; r < R; ++r) s_lds[px * R + r] = sp[it][r];
-    }
-  }
-  for (int i = tid; i < R * C / 4; i += 256)
-    *reinterpret_cast<f32x4*>(w2_lds + i * 4) = *reinterpret_cast<const f32x4*>(a.w2 + i * 4);
-  __syncthreads();
-
-  // gate sweep: item = (tile pixel, channel quad), quad fastest -> C*4 contiguous bytes per pixel
-  constexpr int Q = C / 4;
-  float* outn = a.out + (size_t)n * a.H * a.W * C;
-#pragma unroll 4
-  for (int it = 0; it < Q; ++it) {
-    const int idx = it * 256 + tid;
-    const int q = idx % Q, px = idx / Q;
-    const int h = h0 + (px >> 5), w = w0 + (px & 31);
-    if (h < a.H && w < a.W) {
-      const size_t off = ((size_t)h * a.W + w) * C + q * 4;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + off);
-      f32x4 z = *reinterpret_cast<const f32x4*>(a.b2 + q * 4);
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float sr = s_lds[px * R + r];
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w2_lds + r * C + q * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) z[e] = fmaf(sr, wv[e], z[e]);
-      }
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = xv[e] * (1.0f / (1.0f + expf(-z[e])));
-      *reinterpret_cast<f32x4*>(outn + off) = o;
-    }
-  }
-}
-
 // ---- MaxPool kh x kw, strides (1, sw), TF SAME (padding never wins)            (K6, K7)
-// The 7x7 pool of CAM runs as two separable passes (1x7 then 7x1): max is associative, so the
-// result is bit-identical to the 49-tap window.
+// Generic fallback (stand-alone op API and shapes the fused kernels do not cover).
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in,
                                                       float* __restrict__ out, int N, int H, int Win,
                                                       int Wout, int C, int kh, int kw, int sw, int pt,
@@ -801,6 +639,255 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
       }
     }
     *reinterpret_cast<f32x4*>(out + idx * 4) = m;
+  }
+}
+
+// ---- Context Aggregation Module, one kernel (reference: nets/SqueezeSegV2.py:30-70)
+//   out = x * sigmoid(BN(W2 . relu(BN(W1 . maxpool7x7_s1_SAME(x)))))          C -> C/16 -> C
+// Everything is float32 on the VALU (the two 1x1 convs are 2*C*C/16 MACs per pixel).
+struct CamArgs {
+  const float* x;   // [N,H,W,C]
+  float* out;       // [N,H,W,C]
+  const float* w1;  // [C][R]  BN-folded squeeze weights
+  const float* b1;  // [R]
+  const float* w2;  // [R][C]  BN-folded excitation weights
+  const float* b2;  // [C]
+  int N, H, W, tilesH, tilesW;
+};
+
+// A block owns a TH x 26 pixel tile; its (TH+6) x 32 halo patch is swept in CK-channel chunks.
+// Thread (pc, q) owns patch column pc and channel quad q: it loads the column's TH+6 rows straight
+// into registers (CK*4 contiguous bytes per pixel), KEEPS the TH tile rows for the gate pass,
+// takes the 7-tall column max in registers and publishes only those TH values to LDS; after one
+// barrier the 7-wide row max is read back from LDS and folded into the squeeze sums, which are
+// reduce-scattered over the pixel's CK/4 quad lanes.  x is read from memory exactly once; the
+// 7x7 max is separable and associative, so it is bit-identical to the 49-tap window.
+constexpr int kCamTW = 26, kCamPW = 32;
+
+template <int R, int QP>
+__device__ __forceinline__ float cam_reduce_scatter(float (&p)[R], int q) {
+  // sum p[] over the QP (8 or 16) lanes of a pixel; lane q returns the total of index q & (R-1)
+  if constexpr (QP >= 32) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) p[i] += __shfl_xor(p[i], 16);
+  }
+  if constexpr (QP >= 16) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) p[i] += __shfl_xor(p[i], 8);
+  }
+  float k4[4];
+  if constexpr (R == 8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float send = (q & 4) ? p[i] : p[4 + i];
+      const float keep = (q & 4) ? p[4 + i] : p[i];
+      k4[i] = keep + __shfl_xor(send, 4);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k4[i] = p[i] + __shfl_xor(p[i], 4);
+  }
+  float k2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float send = (q & 2) ? k4[i] : k4[2 + i];
+    const float keep = (q & 2) ? k4[2 + i] : k4[i];
+    k2[i] = keep + __shfl_xor(send, 2);
+  }
+  const float send = (q & 1) ? k2[0] : k2[1];
+  const float keep = (q & 1) ? k2[1] : k2[0];
+  return keep + __shfl_xor(send, 1);
+}
+
+template <int C, int R, int TH, int CK>
+__global__ __launch_bounds__(8 * CK) void cam_kernel(const CamArgs a) {
+  constexpr int TW = kCamTW, PW = kCamPW, PH = TH + 6, NCH = C / CK;
+  constexpr int QP = CK / 4, LQ = QP == 32 ? 5 : QP == 16 ? 4 : 3;  // channel quads per chunk = lanes per pixel
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* colmax = reinterpret_cast<float*>(smem_raw);  // [TH][PW][CK]
+  float* w1c = colmax + TH * PW * CK;                  // [CK][R]
+  const int tid = threadIdx.x;
+  const int pc = tid >> LQ, q = tid & (QP - 1);
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int twi = tile % a.tilesW;
+  tile /= a.tilesW;
+  const int thi = tile % a.tilesH;
+  const int n = tile / a.tilesH;
+  const int h0 = thi * TH, w0 = twi * TW;
+  const float* xn = a.x + (size_t)n * a.H * a.W * C;
+  const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const int w = w0 - 3 + pc;
+  const bool wok = w >= 0 && w < a.W;
+  const bool interior = pc >= 3 && pc < 3 + TW;
+
+  f32x4 v[PH];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int pr = 0; pr < PH; ++pr) {
+      const int h = h0 - 3 + pr;
+      const bool ok = wok && h >= 0 && h < a.H;
+      const float* src = ok ? xn + ((size_t)h * a.W + w) * C + chunk * CK + q * 4 : xn;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+      v[pr] = ok ? t : ninf;
+    }
+  };
+
+  f32x4 xs[NCH][TH];  // this thread's tile pixels (rows h0.., column w), kept for the gate
+  float sp[TH];
+#pragma unroll
+  for (int r = 0; r < TH; ++r) sp[r] = 0.f;
+
+  load_chunk(0);
+#pragma unroll
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      xs[chunk][r] = v[3 + r];
+    }
+    {  // 7-tall running max: triples shared between neighbouring outputs (v_max3_f32)
+      f32x4 t3[PH - 2];
+#pragma unroll
+      for (int i = 0; i < PH - 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t3[i][e] = fmaxf(fmaxf(v[i][e], v[i + 1][e]), v[i + 2][e]);
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        f32x4 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(t3[r][e], t3[r + 3][e]), v[r + 6][e]);
+        *reinterpret_cast<f32x4*>(colmax + (r * PW + pc) * CK + q * 4) = m;
+      }
+    }
+    if (tid < CK * R / 4)
+      *reinterpret_cast<f32x4*>(w1c + tid * 4) =
+          *reinterpret_cast<const f32x4*>(a.w1 + (size_t)chunk * CK * R + tid * 4);
+    __syncthreads();
+    if (chunk + 1 < NCH) load_chunk(chunk + 1);
+    {  // all lanes run the row pass (exterior columns on a clamped window, results unused) so
+       // the cross-lane reduction below is never inside divergent control flow
+      const int pcc = interior ? pc - 3 : 0;
+      float w1r[4][R];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int rr = 0; rr < R; rr += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(w1c + (q * 4 + e) * R + rr);
+          w1r[e][rr] = t[0]; w1r[e][rr + 1] = t[1]; w1r[e][rr + 2] = t[2]; w1r[e][rr + 3] = t[3];
+        }
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const float* src = colmax + (r * PW + pcc) * CK + q * 4;
+        f32x4 m = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int j = 1; j < 7; ++j) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src + j * CK);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], t[e]);
+        }
+        float p[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          float t = m[0] * w1r[0][rr];
+#pragma unroll
+          for (int e = 1; e < 4; ++e) t = fmaf(m[e], w1r[e][rr], t);
+          p[rr] = t;
+        }
+        sp[r] += cam_reduce_scatter<R, QP>(p, q);
+      }
+    }
+    __syncthreads();
+  }
+
+  // squeeze output: + bias, ReLU -> s[TH*TW][R] (aliases colmax; the loop ended on a barrier)
+  float* s_lds = colmax;
+  if (interior && q < R) {
+    const int rq = q;
+    const float b = a.b1[rq];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) s_lds[(r * TW + pc - 3) * R + rq] = fmaxf(sp[r] + b, 0.f);
+  }
+  __syncthreads();
+
+  // gate: out = x * sigmoid(W2 . s + b2) on the register-resident tile pixels
+  if (interior && wok) {
+    float* outn = a.out + (size_t)n * a.H * a.W * C;
+#pragma unroll
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      f32x4 w2r[R];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+        w2r[rr] = *reinterpret_cast<const f32x4*>(a.w2 + rr * C + chunk * CK + q * 4);
+      const f32x4 bz = *reinterpret_cast<const f32x4*>(a.b2 + chunk * CK + q * 4);
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const int h = h0 + r;
+        if (h < a.H) {
+          f32x4 z = bz;
+#pragma unroll
+          for (int rr = 0; rr < R; rr += 4) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s_lds + (r * TW + pc - 3) * R + rr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) z[e] = fmaf(sv[i], w2r[rr + i][e], z[e]);
+          }
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)  // sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, ~1 ulp each)
+            o[e] = xs[chunk][r][e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z[e]));
+          *reinterpret_cast<f32x4*>(outn + ((size_t)h * a.W + w) * C + chunk * CK + q * 4) = o;
+        }
+      }
+    }
+  }
+}
+
+// 3x3 stride (1,2) pool (K7), the only shape SqueezeSegV2 keeps as its own pass.  A thread owns one
+// channel quad of ROWS vertically adjacent outputs: (ROWS+2) x 3 branch-free loads, all in flight
+// together (out-of-image taps are clamped onto an in-window pixel: a duplicate never changes a max).
+template <int ROWS>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in,
+                                                           float* __restrict__ out, int N, int H,
+                                                           int Win, int Wout, int C, int pl) {
+  const int c4n = C >> 2;
+  const int hbn = (H + ROWS - 1) / ROWS;
+  const int total = N * hbn * Wout * c4n;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c4 = idx % c4n;
+  int t = idx / c4n;
+  const int wo = t % Wout;
+  t /= Wout;
+  const int hb = t % hbn;
+  const int n = t / hbn;
+  const int h0 = hb * ROWS;
+  int col[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int ww = wo * 2 - pl + j;
+    col[j] = (ww < 0 ? 0 : ww >= Win ? Win - 1 : ww) * C + c4 * 4;
+  }
+  const float* base = in + (size_t)n * H * Win * C;
+  f32x4 rm[ROWS + 2];
+#pragma unroll
+  for (int r = 0; r < ROWS + 2; ++r) {
+    const int hh = h0 - 1 + r;
+    const float* row = base + (size_t)(hh < 0 ? 0 : hh >= H ? H - 1 : hh) * Win * C;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + col[0]);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + col[1]);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(row + col[2]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rm[r][e] = fmaxf(fmaxf(v0[e], v1[e]), v2[e]);
+  }
+  float* o = out + (((size_t)n * H + h0) * Wout + wo) * C + c4 * 4;
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    if (h0 + i < H) {
+      f32x4 m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(rm[i][e], rm[i + 1][e]), rm[i + 2][e]);
+      *reinterpret_cast<f32x4*>(o + (size_t)i * Wout * C) = m;
+    }
   }
 }
 
