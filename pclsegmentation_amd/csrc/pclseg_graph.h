@@ -160,8 +160,11 @@ inline void op_geometry(Op* op) {
     op->sub[i].nctp = ((n + group - 1) / group) * group;
   }
   const int64_t budget = 64 * 1024;  // default dynamic-LDS limit per block
+  // f16 mode: 40 KiB keeps four blocks per CU resident (160 KiB LDS); worth a second channel chunk
+  // from 64 input channels up (head 77 -> 68 us), not for the 48-channel squeezes (35 -> 36 us)
+  const int64_t budget16 = op->cin_t >= 64 ? 40 * 1024 : budget;
   op->ck16 = 64;
-  while (op->ck16 > 16 && lds_bytes_f16(*op, op->ck16) > budget) op->ck16 /= 2;
+  while (op->ck16 > 16 && lds_bytes_f16(*op, op->ck16) > budget16) op->ck16 /= 2;
   op->ck32 = 32;
   while (op->ck32 > 16 && lds_bytes_f32(*op, op->ck32) > budget) op->ck32 /= 2;
 }
