@@ -9,7 +9,9 @@
 // stride logic :158-181/:215-231, skip bookkeeping :263-277).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <cmath>
@@ -151,9 +153,18 @@ inline void op_geometry(Op* op) {
   else if (nct % 2 == 0) { op->ntw = 2; op->wn = 1; }
   else if (nct == 1) { op->ntw = 1; op->wn = 1; }
   else { op->ntw = 2; op->wn = 2; }
-  // 128-pixel blocks everywhere: WN = 2 -> 4 segments per wave, WN = 1 -> 2 (smaller LDS patch,
-  // more co-resident blocks; measured +2.5 % over 256-pixel blocks for the WN = 1 ops)
-  op->mtw = op->wn == 1 ? 2 : 4;
+  // WN = 2 -> 4 segments per wave (128-pixel blocks).  WN = 1: 256-pixel blocks for the FIRE expand
+  // pairs and the 16-cout ops (fire12/13: 47 -> 45 us, 78 -> 70 us), 128-pixel blocks (smaller LDS
+  // patch, more co-resident blocks) for the rest (head, 32-cout up-convolutions).
+  op->mtw = (op->wn == 1 && op->nsub == 1 && op->ntw != 1) ? 2 : 4;
+  if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw;subname=..."
+    const std::string key = op->sub[0].name + "=";
+    const char* hit = strstr(ov, key.c_str());
+    int a = 0, b = 0, c = 0;
+    if (hit && (hit == ov || hit[-1] == ';') && sscanf(hit + key.size(), "%d,%d,%d", &a, &b, &c) == 3) {
+      op->ntw = a; op->wn = b; op->mtw = c;
+    }
+  }
   const int group = op->ntw * op->wn;
   for (int i = 0; i < op->nsub; ++i) {
     const int n = (op->sub[i].cout + 15) / 16;
