@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per scan from two rocprofv3 PMC passes of `bench.py` (FETCH_SIZE, WRITE_SIZE in
+separate runs, kernel-trace only), summed over the engine's kernels.
+
+usage: make_traffic_json.py <fetch_dir> <write_dir> <scans_profiled> <alg_bytes_per_scan> > rNN_traffic.json
+FETCH_SIZE is doubled (gfx950 counts a 128-byte request as 64 B, MI355X_MICROARCH.md HBM section)."""
+import csv
+import glob
+import json
+import sys
+
+
+def total(d, counter):
+  f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+  return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+             if r["Counter_Name"] == counter and "pclseg" in r["Kernel_Name"])
+
+
+fetch_kb, write_kb = total(sys.argv[1], "FETCH_SIZE"), total(sys.argv[2], "WRITE_SIZE")
+scans, alg = int(sys.argv[3]), int(sys.argv[4])
+print(json.dumps({
+  "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0",
+  "scans_profiled": scans,
+  "FETCH_SIZE_KB_total": fetch_kb,
+  "WRITE_SIZE_KB_total": write_kb,
+  "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+  "hbm_bytes_per_scan": (2 * fetch_kb + write_kb) * 1024 / scans,
+  "alg_bytes_per_scan": alg,
+}, indent=1))
