@@ -286,11 +286,12 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
       // are issued as soon as step s has consumed its slot, so ~D steps of MFMA work cover the
       // L2 latency (one step ahead is far too little: a step is only 12*NTW MFMAs).
       constexpr int D = 2;
+      const int wstep = S.nctp * 1024;  // halfs per K-step of packed fragments
       f16x8 wh[D][NTW], wl[D][NTW];
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int sd = d < nsteps ? d : nsteps - 1;
-        const _Float16* wp = wbase16 + (size_t)sd * S.nctp * 1024;
+        const _Float16* wp = wbase16 + (unsigned)__mul24(sd, wstep);
 #pragma unroll
         for (int nn = 0; nn < NTW; ++nn) {
           wh[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
@@ -304,10 +305,11 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
           if (s < nsteps) {
             int kidx = 4 * s + g;
             if (kidx >= nk) kidx = 0;  // padded K: its weights are zero, read any valid data
-            const int tap = (kidx * inv_ck8) >> 16;
-            const int c8 = kidx - tap * ck8;
-            const int ti = (tap * inv_kw) >> 16;
-            const int koff = (ti * a.PW + (tap - ti * S.nkw)) * CSh + c8 * 8;
+            // 24-bit multiplies (full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it)
+            const int tap = __mul24(kidx, inv_ck8) >> 16;
+            const int c8 = kidx - __mul24(tap, ck8);
+            const int ti = __mul24(tap, inv_kw) >> 16;
+            const int koff = __mul24(__mul24(ti, a.PW) + (tap - __mul24(ti, S.nkw)), CSh) + c8 * 8;
             f16x8 xh[MTW], xl[MTW];
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
               }
             // refill this slot with step s + D (clamped: trailing refills are unused)
             const int sn = (s + D < nsteps) ? s + D : nsteps - 1;
-            const _Float16* wp = wbase16 + (size_t)sn * S.nctp * 1024;
+            const _Float16* wp = wbase16 + (unsigned)__mul24(sn, wstep);
 #pragma unroll
             for (int nn = 0; nn < NTW; ++nn) {
               wh[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
