@@ -138,3 +138,41 @@ def test_product_code_never_imports_the_oracle():
       if f.endswith((".py", ".h", ".hip")):
         src = open(os.path.join(d, f)).read()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_tf_exporter_walks_reference_attribute_paths(tmp_path):
+  """tools/export_tf_weights.collect_weights reads a (stand-in) Keras object tree by the
+  reference's attribute paths; the resulting file round-trips through load_model."""
+  import types
+  import pclsegmentation_amd as P
+  from pclsegmentation_amd.tools.export_tf_weights import collect_weights
+
+  class Var:                       # quacks like tf.Variable
+    def __init__(self, a):
+      self._a = a
+    def numpy(self):
+      return self._a
+
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  spec = model.weight_spec()
+  from pclsegmentation_amd.nets.weights import synthetic_weights
+  want = synthetic_weights(spec, seed=7)
+  root = types.SimpleNamespace()
+  for w in spec:
+    *attrs, leaf = w.path.split("/")
+    obj = root
+    for a in attrs:
+      if not hasattr(obj, a):
+        setattr(obj, a, types.SimpleNamespace())
+      obj = getattr(obj, a)
+    setattr(obj, leaf, Var(want[w.path].astype(np.float64)))     # dtype is normalised to float32
+  got = collect_weights(root, spec)
+  assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
+  assert all(v.dtype == np.float32 for v in got.values())
+  model.set_weights(got)
+  model.save(str(tmp_path / "m.npz"))
+  back = P.load_model(str(tmp_path / "m.npz"))
+  assert back.arch_name() == "squeezesegv2" and np.array_equal(back.weights["conv14/kernel"], want["conv14/kernel"])
+  del root.fire9.expand3x3_bn.moving_variance
+  with pytest.raises(ValueError, match="fire9.expand3x3_bn.moving_variance"):
+    collect_weights(root, spec)
