@@ -411,9 +411,15 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
     HIP_TRY(h, hipEventRecord(h->ev_in, h->stream));
     for (int l = 0; l < h->nlanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_in, 0));
   }
-  int mbi = 0;
-  for (int s0 = 0; s0 < n; s0 += g.micro_batch, ++mbi) {
-    const int cnt = std::min(g.micro_batch, n - s0);
+  // Micro-batches: at most g.micro_batch scans each, their number rounded up to a multiple of the
+  // lane count and the scans spread evenly, so every lane gets the same work (32 scans, 3 lanes:
+  // 4,4,4,4,4,3,3,3,3 instead of eight 4s dealt 3/3/2).
+  int nmb = (n + g.micro_batch - 1) / g.micro_batch;
+  if (multi && nmb > 1) nmb = std::min(n, ((nmb + h->nlanes - 1) / h->nlanes) * h->nlanes);
+  const int mb_lo = n / nmb, mb_extra = n % nmb;  // the first mb_extra micro-batches take one more
+  int s0 = 0;
+  for (int mbi = 0; mbi < nmb; ++mbi) {
+    const int cnt = mb_lo + (mbi < mb_extra ? 1 : 0);
     const size_t P = (size_t)cnt * HW;
     const int lane = mbi % h->nlanes;
     const hipStream_t stream = multi ? h->lane_stream[lane] : h->stream;
@@ -437,6 +443,7 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
     if (rc) return rc;
     h->last_count = cnt;
     h->d_arena = h->d_arena_lane[lane];
+    s0 += cnt;
   }
   if (multi) {  // the caller's stream continues only after every lane has drained
     for (int l = 0; l < h->nlanes; ++l) {
