@@ -17,6 +17,7 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True   # /root/reference is read-only by contract: no __pycache__ there
 REF = "/root/reference/pcl_segmentation/configs"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs.json")
 

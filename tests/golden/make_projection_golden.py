@@ -9,10 +9,12 @@ proj_xyz, proj_remission, proj_idx (float32 / int32, -1 = no data).
 """
 import importlib.util
 import os
+import sys
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True   # /root/reference is read-only by contract: no __pycache__ there
 REF = "/root/reference/dataset_convert/laserscan_semantic_kitti.py"
 
 CASES = [
