@@ -94,13 +94,14 @@ def main():
     raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-  torch.cuda.set_device(local_rank)
-  dev = torch.device("cuda", local_rank)
+  dev_index = local_rank % torch.cuda.device_count()   # identity on a node with one GPU per rank
+  torch.cuda.set_device(dev_index)
+  dev = torch.device("cuda", dev_index)
 
   model_name, config_name, h, w, batch, pvalid, bound = WORKLOADS[args.workload]
   if args.batch:
     batch = args.batch
-  mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=local_rank,
+  mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=dev_index,
                                   micro_batch=args.micro_batch)
   spec = model.weight_spec()
   weights = synthetic_weights(spec, 4321) if rank == 0 else None

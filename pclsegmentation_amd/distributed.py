@@ -24,12 +24,12 @@ def init_process_group(backend=None):
   backend defaults to nccl (= RCCL on ROCm) when a GPU is visible, else gloo."""
   rank, local_rank, world = env_world()
   if world > 1 and not dist.is_initialized():
-    if backend is None:
-      backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:   # PCLSEG_DIST_BACKEND=gloo: test aid (several ranks sharing one GPU)
+      backend = os.environ.get("PCLSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
-      torch.cuda.set_device(local_rank)
+      torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
   return rank, local_rank, world
 
