@@ -78,7 +78,7 @@ class MeanIoU:
 
 def evaluation(arg):
   if arg.path_to_model:
-    model = load_model(arg.path_to_model)
+    model = load_model(arg.path_to_model, model_name=arg.model, config_name=arg.config)   # .npz or SavedModel dir
     config = model.mc
   else:
     config, model = load_model_config(arg.model, arg.config)
@@ -113,7 +113,7 @@ def main(argv=None):
   parser.add_argument("-i", "--image_set", type=str, default="val",
                       help="Default: `val`. But can also be train, val or test")
   parser.add_argument("-t", "--eval_dir", type=str, default=None, help="(unused: no TensorBoard logs are written)")
-  parser.add_argument("-p", "--path_to_model", type=str, default=None, help="Path to the model (.npz)")
+  parser.add_argument("-p", "--path_to_model", type=str, default=None, help="Path to the model: .npz file or reference SavedModel directory")
   parser.add_argument("-m", "--model", type=str, default="squeezesegv2",
                       help="Model name either `squeezesegv2`, `darknet53`, `darknet21`")
   parser.add_argument("-n", "--config", type=str, default="squeezesegv2",

@@ -46,7 +46,7 @@ def inference(arg):
   if not files:
     raise SystemExit("no input files match %r" % arg.input_path)
   if arg.path_to_model:
-    model = load_model(arg.path_to_model)
+    model = load_model(arg.path_to_model, model_name=arg.model, config_name=arg.config)   # .npz or SavedModel dir
     config = model.mc
     if arg.model and model.arch_name() != arg.model.lower() and not (
         arg.model.lower().startswith("darknet") and model.arch_name().startswith("darknet")):
@@ -107,7 +107,7 @@ def main(argv=None):
                       help="Model name either `squeezesegv2`, `darknet53`, `darknet21`")
   parser.add_argument("-t", "--output_dir", type=str, required=True,
                       help="Directory where to write the model predictions and visualizations")
-  parser.add_argument("-p", "--path_to_model", type=str, default=None, help="Path to the model (.npz)")
+  parser.add_argument("-p", "--path_to_model", type=str, default=None, help="Path to the model: .npz file or reference SavedModel directory")
   parser.add_argument("-c", "--config", type=str, default=None,
                       help="Config name (config_map key); default: the model's namesake")
   parser.add_argument("--batch", type=int, default=32, help="scans per forward call")

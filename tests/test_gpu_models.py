@@ -204,3 +204,23 @@ def test_full_size_darknet21_nuscenes_shape(cuda):
   check_against(preds[2], logits[2], mask[2], ologits[0], opred[0], (srt[..., -1] - srt[..., -2]), 10)
   p1, l1, _, _ = run_engine(model, raw[2:3])
   assert np.array_equal(p1[0], preds[2]) and np.array_equal(l1[0], logits[2])
+
+
+def test_inference_cli_reads_a_savedmodel_directory(cuda, tmp_path):
+  """-p may be a reference SavedModel directory (inference.py:39): the tensor bundle is read
+  without TensorFlow (fixture from tests/bundle_writer.py — reader parity is unpinned)."""
+  from pclsegmentation_amd import inference as cli
+  from tests.test_savedmodel import _make_savedmodel
+  g = np.load(os.path.join(GOLDEN, "model_ssv2_real_32x240.npz"))
+  src = tmp_path / "scans"
+  src.mkdir()
+  np.save(str(src / "scan0.npy"), g["raw"][0].astype(np.float64))
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  _make_savedmodel(str(tmp_path / "saved"), model.weight_spec(), model.weights)
+  out = tmp_path / "out"
+  cli.main(["-d", str(src / "*.npy"), "-m", "squeezesegv2", "-t", str(out), "-p", str(tmp_path / "saved"),
+            "--no_plots"])
+  pred = np.load(str(out / "pred_scan0.npy"))
+  decided = g["margin"][0] > MARGIN
+  assert np.array_equal(pred[decided], g["preds"][0][decided])

@@ -1,0 +1,107 @@
+"""TensorFlow-free SavedModel weight reader (pclsegmentation_amd/savedmodel.py) — SURVEY.md §8(f)
+rank 1.  PARITY UNPINNED: no TensorFlow-written bundle exists in this image; the fixtures come
+from tests/bundle_writer.py, an independent writer of the published format."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import pclsegmentation_amd as P
+from pclsegmentation_amd import savedmodel as SM
+from pclsegmentation_amd.nets.weights import synthetic_weights
+from tests import bundle_writer as BW
+
+
+def test_crc32c_and_mask_known_answers():
+  assert SM.crc32c(b"123456789") == 0xE3069283          # RFC 3720 appendix B.4 check value
+  assert SM.crc32c(b"") == 0
+  assert SM.mask_crc(0) == 0xA282EAD8
+  assert SM.crc32c(b"6789", SM.crc32c(b"12345")) == 0xE3069283
+
+
+def test_snappy_literal_and_overlapping_copy():
+  stream = bytes([9, (3 - 1) << 2]) + b"abc" + bytes([((6 - 4) << 2) | 1, 3])
+  assert SM.snappy_decompress(stream) == b"abcabcabc"
+  blob = bytes(range(256)) * 3
+  assert SM.snappy_decompress(BW.snappy_literal_only(blob)) == blob
+  with pytest.raises(SM.BundleError):
+    SM.snappy_decompress(bytes([5, 1, 9]))                # copy before any output
+
+
+@pytest.mark.parametrize("snappy", [False, True], ids=["plain", "snappy"])
+def test_table_round_trip_many_blocks(tmp_path, snappy):
+  keys = sorted(("layer_%03d/sub_%d/kernel/.ATTRIBUTES/VARIABLE_VALUE" % (i // 4, i % 4)).encode() for i in range(300))
+  tw = BW.TableWriter(block_size=256, snappy=snappy)
+  for i, k in enumerate(keys):
+    tw.add(k, struct.pack("<I", i) * (1 + i % 5))
+  path = str(tmp_path / "t.index")
+  blob = tw.finish()
+  open(path, "wb").write(blob)
+  got = SM.read_table(path)
+  assert [k for k, _ in got] == keys
+  assert all(v == struct.pack("<I", i) * (1 + i % 5) for i, (_, v) in enumerate(got))
+  bad = bytearray(blob)
+  bad[40] ^= 0x55                                          # inside the first data block
+  open(path, "wb").write(bytes(bad))
+  with pytest.raises(SM.BundleError, match="checksum"):
+    SM.read_table(path)
+  open(path, "wb").write(blob[:-1] + b"\0")
+  with pytest.raises(SM.BundleError, match="magic"):
+    SM.read_table(path)
+
+
+def _make_savedmodel(root, spec, weights, with_graph=True, snappy=False):
+  """Variables addressed the two ways Keras does: by attribute path, and (conv1, bn1) through a
+  ``layer_with_weights-N`` alias that TensorFlow picked as the checkpoint key."""
+  alias = {"conv1": "layer_with_weights-0", "bn1": "layer_with_weights-1"}
+  keys, tensors = {}, {}
+  for w in spec:
+    top, rest = w.path.split("/", 1)
+    prefix = alias[top] + "/" + rest if (with_graph and top in alias) else w.path
+    keys[w.path] = prefix + "/.ATTRIBUTES/VARIABLE_VALUE"
+    tensors[keys[w.path]] = weights[w.path]
+  tensors["save_counter/.ATTRIBUTES/VARIABLE_VALUE"] = np.array(3, np.int64)
+  graph = BW.object_graph(keys, [("", a, t) for t, a in alias.items()]) if with_graph else None
+  BW.write_bundle(os.path.join(root, "variables", "variables"), tensors, graph, snappy=snappy)
+  open(os.path.join(root, "saved_model.pb"), "wb").write(b"")   # present in a real export; never read
+
+
+@pytest.mark.parametrize("variant", ["graph", "no_graph", "snappy"])
+def test_savedmodel_weights_round_trip(tmp_path, variant):
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  spec = model.weight_spec()
+  want = synthetic_weights(spec, seed=11)
+  root = str(tmp_path / "model")
+  _make_savedmodel(root, spec, want, with_graph=variant != "no_graph", snappy=variant == "snappy")
+  assert SM.is_savedmodel_dir(root)
+  reader = SM.BundleReader(os.path.join(root, "variables", "variables"))
+  assert reader.get_tensor("save_counter/.ATTRIBUTES/VARIABLE_VALUE") == 3
+  if variant != "no_graph":
+    g = SM.ObjectGraph(reader.get_strings(SM.OBJECT_GRAPH_KEY)[0])
+    assert g.checkpoint_key("conv1/kernel").startswith("layer_with_weights-0/")
+    assert g.checkpoint_key("fire9/expand3x3_bn/moving_variance").startswith("fire9/expand3x3_bn/")
+  got = SM.load_savedmodel_weights(root, spec, verify_crc=variant == "graph")   # pure-Python CRC: once is enough
+  assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
+  loaded = P.load_model(root, model_name="squeezesegv2", config_name="squeezesegv2")
+  assert np.array_equal(loaded.weights["conv14/kernel"], want["conv14/kernel"])
+  with pytest.raises(ValueError, match="model_name"):
+    P.load_model(root)
+
+
+def test_savedmodel_errors_name_the_tensor(tmp_path):
+  mc, model = P.load_model_config("darknet21", "darknet21")
+  spec = model.weight_spec()
+  want = synthetic_weights(spec, seed=2)
+  broken = dict(want)
+  del broken["enc3/residual_1/bn2/moving_variance"]
+  root = str(tmp_path / "m1")
+  _make_savedmodel(root, [w for w in spec if w.path in broken], broken)
+  with pytest.raises(ValueError, match="enc3/residual_1/bn2/moving_variance"):
+    SM.load_savedmodel_weights(root, spec)
+  wrong = dict(want)
+  wrong["head/kernel" if "head/kernel" in want else spec[-1].path] = np.zeros((1, 1, 2, 2), np.float32)
+  root2 = str(tmp_path / "m2")
+  _make_savedmodel(root2, spec, wrong)
+  with pytest.raises(ValueError, match="shape"):
+    SM.load_savedmodel_weights(root2, spec)
