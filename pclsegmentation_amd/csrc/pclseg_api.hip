@@ -221,6 +221,7 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
     ny += d.ny;
   }
   a.ny = ny;
+  a.group_major = 0;
   int wo, pl, ho, pt;
   same_pad(Win, op.pkw, op.sw, &wo, &pl);
   same_pad(H, op.pkh, 1, &ho, &pt);
@@ -262,6 +263,17 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   }
   const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
   if (lds > 64 * 1024) return hipErrorInvalidValue;
+  {
+    // A layer whose packed weights fit an XCD's 4 MB L2 keeps them there under any order, so the
+    // order is spent on the input patches (tile-major).  Darknet's deep layers (up to 19 MB of
+    // fragments) would re-stream the weights from the Infinity Cache for every pixel tile:
+    // group-major makes the blocks resident on an XCD read the same fragments together.
+    double wbytes = 0;
+    for (int i = 0; i < op.nsub; ++i)
+      wbytes += (double)op.sub[i].nkh * op.sub[i].nkw * op.cin_t * op.sub[i].nctp * 16 * 4.0;
+    static const int gm = getenv("PCLSEG_GROUP_MAJOR") ? atoi(getenv("PCLSEG_GROUP_MAJOR")) : -1;
+    a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
+  }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
   if (op.kind == OP_HEAD)

@@ -73,6 +73,7 @@ struct ConvArgs {
   int inv_pw;  // ceil(2^20 / PW): pixel index -> patch row by multiply-shift
   int nsub;
   int ny;      // blocks per pixel tile (all sub-convs' cout groups)
+  int group_major;  // block order, see conv_kernel
   ConvSub sub[2];
 };
 
@@ -110,10 +111,20 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   const int p = lane & 15;  // pixel within the 16-pixel segment
   const int g = lane >> 4;  // k-group (operands) / cout quad (accumulator)
 
-  // logical id = tile * ny + cout group: the groups of one tile are neighbours on one XCD
+  // Each XCD works on a contiguous range of logical ids.  tile-major (id = tile * ny + group): the
+  // cout groups of one tile run back to back and share the staged input patch in L2 (activation-
+  // heavy layers).  group-major (id = group * ntiles + tile): the ~128 blocks resident on an XCD
+  // stream the SAME weight fragments, which then stay in its 4 MB L2 (weight-heavy layers).
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  int tile = lid / a.ny;
-  const int by = lid - tile * a.ny;
+  int tile, by;
+  if (a.group_major) {
+    const int ntiles = gridDim.x / a.ny;
+    by = lid / ntiles;
+    tile = lid - by * ntiles;
+  } else {
+    tile = lid / a.ny;
+    by = lid - tile * a.ny;
+  }
   const int twi = tile % a.tilesW;
   tile /= a.tilesW;
   const int thi = tile % a.tilesH;
