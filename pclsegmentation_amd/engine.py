@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpclseg.so")
+LIB_PATH = os.environ.get("PCLSEG_LIB") or os.path.join(_HERE, "libpclseg.so")   # override: A/B of two builds
 
 OK = 0
 ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5, -6
