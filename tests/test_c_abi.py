@@ -1,0 +1,33 @@
+"""The drop-in boundary used from plain C: tests/c_abi/consumer.c is compiled with gcc -std=c99
+against include/pclseg.h and linked with libpclseg.so — no Python, torch or C++ on the caller side."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "pclsegmentation_amd")
+
+
+@pytest.fixture(scope="module")
+def consumer(tmp_path_factory):
+  if not os.path.isfile(os.path.join(LIBDIR, "libpclseg.so")):
+    pytest.fail("libpclseg.so is not built (run `make`)")
+  exe = str(tmp_path_factory.mktemp("c_abi") / "consumer")
+  subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1",
+                         "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "consumer.c"),
+                         "-L", LIBDIR, "-lpclseg", "-lm", "-Wl,-rpath," + LIBDIR, "-o", exe])
+  return exe
+
+
+def test_c_consumer_plan_and_error_codes(consumer):
+  out = subprocess.run([consumer, "plan"], capture_output=True, text=True, timeout=120)
+  assert out.returncode == 0, out.stderr
+  assert "plan ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_consumer_forward(consumer):
+  out = subprocess.run([consumer, "forward"], capture_output=True, text=True, timeout=300)
+  assert out.returncode == 0, out.stderr + out.stdout
+  assert "forward ok" in out.stdout
