@@ -80,6 +80,7 @@ def main():
   ap.add_argument("--batch", type=int, default=0, help="scans per GPU per step (0 = workload default)")
   ap.add_argument("--micro-batch", type=int, default=0)
   ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
+  ap.add_argument("--host-io", action="store_true", help="also time the step with host buffers (PCIe-inclusive)")
   args = ap.parse_args()
 
   import torch
@@ -183,6 +184,18 @@ def main():
                  "math": "f16x3 products, f32 accumulate", "micro_batch": info["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")), "parallelism": "batch-sharded x%d" % world},
       "roofline": roof,
     }
+    if world == 1 and args.host_io:
+      # informational only (never `value`): the same step when the boundary hands over HOST
+      # buffers, i.e. raw scans cross PCIe in and int32 predictions cross it back
+      h_scans = scans.cpu().numpy()
+      h_preds = np.empty((batch, h, w), np.int32)
+      for _ in range(2):
+        eng.forward_raw(h_scans, batch, h_preds, None, None, None, mem=E.MEM_HOST)
+      t1 = time.perf_counter()
+      for _ in range(args.steps):
+        eng.forward_raw(h_scans, batch, h_preds, None, None, None, mem=E.MEM_HOST)
+      out["host_boundary"] = {"value": round(batch * args.steps / (time.perf_counter() - t1), 1), "unit": "scans/s",
+                              "note": "pageable host buffers in and out over PCIe, synchronous call"}
     if world == 1 and args.cpu_seconds > 0:
       out["cpu_baseline"] = cpu_baseline(model_name, mc, weights, h, w, pvalid, args.cpu_seconds)
     print(json.dumps(out), flush=True)
