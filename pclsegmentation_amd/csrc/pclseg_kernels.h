@@ -677,43 +677,54 @@ struct CamArgs {
 // 7x7 max is separable and associative, so it is bit-identical to the 49-tap window.
 constexpr int kCamTW = 26, kCamPW = 32;
 
+// Cross-lane sum of p[] over the QP (8 or 16) lanes of a pixel on the DPP network (one VALU
+// instruction per exchange, no LDS round trip as with ds_bpermute).  The lanes of a pixel are
+// one DPP row (QP = 16) or half a row (QP = 8).  Pairings: row_mirror (i <-> 15-i), row_half_mirror
+// (i <-> 7-i), quad_perm [2,3,0,1] and [1,0,3,2]; each step either adds the partner's copy
+// (all-reduce) or keeps one half of the values and adds the partner's other half
+// (reduce-scatter).  `u` is the lane's index among the lanes that still hold distinct data.
+// Returns, in lane q < R, the total of p[q]; must be called from convergent code.
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 template <int R, int QP>
 __device__ __forceinline__ float cam_reduce_scatter(float (&p)[R], int q) {
-  // sum p[] over the QP (8 or 16) lanes of a pixel; lane q returns the total of index q & (R-1)
-  if constexpr (QP >= 32) {
+  static_assert((R == 4 || R == 8) && (QP == 8 || QP == 16), "unsupported CAM geometry");
+  constexpr int kRowMirror = 0x140, kHalfMirror = 0x141, kXor2 = 0x4E, kXor1 = 0xB1;
+  int u = q;
+  if constexpr (QP == 16) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) p[i] += __shfl_xor(p[i], 16);
-  }
-  if constexpr (QP >= 16) {
-#pragma unroll
-    for (int i = 0; i < R; ++i) p[i] += __shfl_xor(p[i], 8);
+    for (int i = 0; i < R; ++i) p[i] += dpp_read<kRowMirror>(p[i]);
+    u = (u & 8) ? 15 - u : u;
   }
   float k4[4];
   if constexpr (R == 8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float send = (q & 4) ? p[i] : p[4 + i];
-      const float keep = (q & 4) ? p[4 + i] : p[i];
-      k4[i] = keep + __shfl_xor(send, 4);
+      const float send = (u & 4) ? p[i] : p[4 + i];
+      const float keep = (u & 4) ? p[4 + i] : p[i];
+      k4[i] = keep + dpp_read<kHalfMirror>(send);   // partner 7-u is in the other half
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k4[i] = p[i] + __shfl_xor(p[i], 4);
+    for (int i = 0; i < 4; ++i) k4[i] = p[i] + dpp_read<kHalfMirror>(p[i]);
+    u = (u & 4) ? 7 - u : u;
   }
   float k2[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float send = (q & 2) ? k4[i] : k4[2 + i];
-    const float keep = (q & 2) ? k4[2 + i] : k4[i];
-    k2[i] = keep + __shfl_xor(send, 2);
+    const float send = (u & 2) ? k4[i] : k4[2 + i];
+    const float keep = (u & 2) ? k4[2 + i] : k4[i];
+    k2[i] = keep + dpp_read<kXor2>(send);
   }
-  const float send = (q & 1) ? k2[0] : k2[1];
-  const float keep = (q & 1) ? k2[1] : k2[0];
-  return keep + __shfl_xor(send, 1);
+  const float send = (u & 1) ? k2[0] : k2[1];
+  const float keep = (u & 1) ? k2[1] : k2[0];
+  return keep + dpp_read<kXor1>(send);   // lane holds index u (R = 8: bits 4,2,1; R = 4: bits 2,1)
 }
 
 template <int C, int R, int TH, int CK>
-__global__ __launch_bounds__(8 * CK) void cam_kernel(const CamArgs a) {
+__global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
   constexpr int TW = kCamTW, PW = kCamPW, PH = TH + 6, NCH = C / CK;
   constexpr int QP = CK / 4, LQ = QP == 32 ? 5 : QP == 16 ? 4 : 3;  // channel quads per chunk = lanes per pixel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
