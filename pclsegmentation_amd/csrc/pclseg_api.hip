@@ -304,10 +304,10 @@ hipError_t launch_pool(const float* in, float* out, int N, int H, int Win, int C
   same_pad(H, kh, 1, &ho, &pt);
   if (kh == 3 && kw == 3 && sw == 2) {
     constexpr int kRows = 4;
-    const size_t items = (size_t)N * ((H + kRows - 1) / kRows) * wo * (C / 4);
-    if (items > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((maxpool3x3s2_kernel<kRows>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
-                       in, out, N, H, Win, wo, C, pl);
+    const unsigned hbn = (unsigned)((H + kRows - 1) / kRows);
+    if (hbn > 65535u || (unsigned)N > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((maxpool3x3s2_kernel<kRows>), dim3((unsigned)((wo * (C / 4) + 255) / 256), hbn, (unsigned)N),
+                       dim3(256), 0, s, in, out, N, H, Win, wo, C, pl);
     return hipGetLastError();
   }
   const size_t total = (size_t)N * H * wo * (C / 4);

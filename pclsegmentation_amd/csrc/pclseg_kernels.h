@@ -873,18 +873,15 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in,
                                                            float* __restrict__ out, int N, int H,
                                                            int Win, int Wout, int C, int pl) {
+  // grid = (ceil(Wout * C/4 / 256), row blocks, N): no integer division per thread (there is no
+  // hardware divide: one costs ~25 VALU instructions, more than the 40 max3 this thread does)
   const int c4n = C >> 2;
-  const int hbn = (H + ROWS - 1) / ROWS;
-  const int total = N * hbn * Wout * c4n;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c4 = idx % c4n;
-  int t = idx / c4n;
-  const int wo = t % Wout;
-  t /= Wout;
-  const int hb = t % hbn;
-  const int n = t / hbn;
-  const int h0 = hb * ROWS;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= Wout * c4n) return;
+  const int wo = (c4n & (c4n - 1)) == 0 ? x >> (31 - __builtin_clz(c4n)) : x / c4n;
+  const int c4 = x - wo * c4n;
+  const int n = blockIdx.z;
+  const int h0 = blockIdx.y * ROWS;
   int col[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
