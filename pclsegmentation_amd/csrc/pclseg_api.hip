@@ -245,6 +245,25 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
     // LDS-free streaming GEMM; every wave owns mtw*16 pixels x ntw*16 couts
     // one block column covers ALL couts (nctp <= 4 tiles), so the input is read exactly once
     const int ntw = op.sub[0].nctp;
+    static const int splitk_min = getenv("PCLSEG_SPLITK") ? atoi(getenv("PCLSEG_SPLITK")) : 256;
+    if (splitk_min > 0 && op.cin_t >= splitk_min && ntw >= 3) {
+      // deep squeezes (256..512 channels -> 48/64, 64x128 pixels): the block's four waves split
+      // the channels (conv1x1_direct_kernel, SPLITK): fire6/7 14.6/18.1 -> 10.6/13.7 us,
+      // fire9/10 22 -> 20 us; no gain for the 32-cout layers
+      const int mtw = 2;
+      dim3 grid((unsigned)((a.Win + mtw * 16 - 1) / (mtw * 16)), 1u);
+      const size_t lds = (size_t)4 * mtw * ntw * 1024;
+      const bool res = a.res1 != nullptr;
+#define PCLSEG_SK(MTW_, NTW_) \
+      do { if (res) hipLaunchKernelGGL((conv1x1_direct_kernel<MTW_, NTW_, true, true>), grid, dim3(kConvThreads), lds, s, a); \
+           else hipLaunchKernelGGL((conv1x1_direct_kernel<MTW_, NTW_, false, true>), grid, dim3(kConvThreads), lds, s, a); } while (0)
+      switch (ntw) {
+        case 3: PCLSEG_SK(2, 3); break;
+        default: PCLSEG_SK(2, 4); break;
+      }
+#undef PCLSEG_SK
+      return hipGetLastError();
+    }
     const int mtw = ntw == 4 ? 1 : 2;  // 4 cout tiles x 2 segments would spill at 128 VGPRs
     const int px_per_block = 4 * mtw * 16;
     dim3 grid((unsigned)((a.Win + px_per_block - 1) / px_per_block), 1u);

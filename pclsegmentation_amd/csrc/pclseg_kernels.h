@@ -514,15 +514,19 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
 // No barriers, no LDS -> occupancy is bounded by registers only.  Uses the same packed weight
 // fragments as conv_kernel (K-step t of the packed array covers channel groups 4t .. 4t+3 when
 // the packing chunk is 32 or 64 channels).  Requires Cin % 8 == 0.
-template <int MTW, int NTW, bool RES>
-__global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const ConvArgs a) {
+// SPLITK (deep layers: many channels, few pixels): the four waves of a block share one run of
+// MTW*16 pixels and split the channels into four contiguous quarters, then add their partial
+// accumulators through LDS — four times the waves per pixel for the memory system to work with,
+// and each weight fragment is fetched once per MTW*16 pixels instead of once per wave.
+template <int MTW, int NTW, bool RES, bool SPLITK = false>
+__global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) void conv1x1_direct_kernel(const ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane & 15, g = lane >> 4;
   const ConvSub& S = a.sub[0];
   const int total = a.Win;  // flattened pixel count (N = H = 1 view)
-  const int pix0 = ((int)blockIdx.x * 4 + wave) * (MTW * 16);
+  const int pix0 = SPLITK ? (int)blockIdx.x * (MTW * 16) : ((int)blockIdx.x * 4 + wave) * (MTW * 16);
   if (pix0 >= total) return;
   const int ct0 = blockIdx.y * NTW;
   const int cin8 = a.Cin >> 3;
@@ -563,8 +567,14 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const C
     }
   };
 
-  load_step(0);
-  for (int t = 0; t < nsteps; ++t) {
+  int t_lo = 0, t_hi = nsteps;
+  if constexpr (SPLITK) {
+    const int per = (nsteps + 3) >> 2;
+    t_lo = wave * per;
+    t_hi = t_lo + per < nsteps ? t_lo + per : nsteps;
+  }
+  if (t_lo < t_hi) load_step(t_lo);
+  for (int t = t_lo; t < t_hi; ++t) {
     // split this step's activations, keep its weights, then refill the raw registers
     f16x8 xh[MTW], xl[MTW], ch[NTW], cl[NTW];
 #pragma unroll
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const C
     }
 #pragma unroll
     for (int nn = 0; nn < NTW; ++nn) { ch[nn] = wh[nn]; cl[nn] = wl[nn]; }
-    if (t + 1 < nsteps) load_step(t + 1);
+    if (t + 1 < t_hi) load_step(t + 1);
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -590,6 +600,42 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv1x1_direct_kernel(const C
         acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[nn], xl[m], acc[m][nn], 0, 0, 0);
         acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[nn], xh[m], acc[m][nn], 0, 0, 0);
       }
+  }
+
+  if constexpr (SPLITK) {
+    // partial accumulators -> LDS [wave][tile][lane]; tile t is finished by wave t & 3
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
+    constexpr int NT = MTW * NTW;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NTW; ++nn) red[(wave * NT + m * NTW + nn) * 64 + lane] = acc[m][nn];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NTW; ++nn) {
+        constexpr int dummy = 0; (void)dummy;
+        const int tile = m * NTW + nn;
+        if ((tile & 3) != wave) continue;
+        f32x4 v = red[tile * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += red[(w * NT + tile) * 64 + lane];
+        const int co = (ct0 + nn) * 16 + g * 4;
+        if (pvalid[m] && co < S.Cout) {
+          const size_t px = (size_t)(pix0 + m * 16 + p);
+          v += *reinterpret_cast<const f32x4*>(S.bias + co);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
+          if constexpr (RES) if (a.res1) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + px * a.res1_C + S.co_off + co);
+            v = a.res1_mul ? v * r : v + r;
+          }
+          *reinterpret_cast<f32x4*>(a.out + px * a.out_C + S.co_off + co) = v;
+        }
+      }
+    return;
   }
 
   // epilogue (two passes: residual operands first, then the stores; see conv_kernel)
