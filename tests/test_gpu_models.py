@@ -95,9 +95,9 @@ def test_micro_batch_invariance(cuda):
   """Any split of the batch into micro-batches gives bit-identical outputs."""
   mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
   model.init_weights(4321)
-  raw = synthetic_scans(5, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=5)
+  raw = synthetic_scans(7, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=5)
   ref = None
-  for mb in (1, 2, 5, 16):
+  for mb in (1, 2, 3, 5, 16):     # 7 scans: uneven splits, more / fewer micro-batches than lanes
     model._drop_engines()
     preds, logits, _, _ = run_engine(model, raw, micro_batch=mb)
     if ref is None:
