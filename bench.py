@@ -2,7 +2,10 @@
 """Benchmark of the hot path: LiDAR scans/s of the forward pass on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 without a torchrun environment: bench.py starts N fresh rank processes itself
+  (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...) BEFORE
+  anything in this process touches the GPU, and exits with their status; launched by the driver
+  under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 One step = pclseg_forward_raw over one batch of synthetic raw scans already resident in HBM
 (normalise+mask -> network -> argmax -> masked int32 predictions, also left in HBM).  Default
@@ -36,39 +39,67 @@ WORKLOADS = {
 }
 
 
+def _cpu_leg(net, mc, raw, threads, batch, budget_s, max_scans):
+  """scans/s of the CPU stand-in at a given thread count and batch size (bounded sample)."""
+  import torch
+  from oracle import np_oracle as O
+  torch.set_num_threads(threads)
+  none_index = mc.CLASSES.index("None")
+
+  def one_batch(i):
+    chunk = raw[(i * batch) % raw.shape[0]:][:batch]
+    lidar, mask = O.normalize_and_mask(chunk, mc.INPUT_MEAN, mc.INPUT_STD)
+    net(lidar.astype(np.float32), mask, none_index)
+    return chunk.shape[0]
+
+  one_batch(0)  # warm-up (oneDNN primitive creation)
+  done, i, t0 = 0, 0, time.perf_counter()
+  while True:
+    done += one_batch(i)
+    i += 1
+    el = time.perf_counter() - t0
+    if el >= budget_s or done >= max_scans:
+      break
+  return round(done / el, 3), done
+
+
 def cpu_baseline(model_name, mc, weights, h, w, pvalid, budget_s):
   """Time the CPU stand-in for the reference's TF2-CPU path on this box's host cores:
   oracle/torch_ref.py (PyTorch-CPU/oneDNN expression of the identical graph, identical weights).
-  Bounded sample: scans are added until ~budget_s of CPU work has been spent."""
+  Bounded sample.  Legs: all usable cores at batch 2 (`value`), the reference's
+  own loop shape B = 1 (inference.py:44-75) at the same thread count, one thread at B = 1, and —
+  for the SqueezeSegV2 headline — config C1 on the reference's real 32x240 sample scans."""
   import torch
-  from oracle import np_oracle as O
   from oracle.torch_ref import TorchNet
   from pclsegmentation_amd.utils.synthetic import synthetic_scans
   # oneDNN scales poorly past a few dozen threads on these small convolutions (256 threads ran
   # 20x slower than 8 on the GPU box), so the pool is capped; `cores` reports the threads used
   cores = min(os.cpu_count() or 1, 32)
-  torch.set_num_threads(cores)
   net = TorchNet(model_name, weights, num_layers=mc.get("NUM_LAYERS"),
                  output_stride=mc.get("OUTPUT_STRIDE", 16))
   raw = synthetic_scans(2, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid, seed=77)
-  none_index = mc.CLASSES.index("None")
-
-  def one_batch():
-    lidar, mask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
-    net(lidar.astype(np.float32), mask, none_index)
-
-  one_batch()  # warm-up (oneDNN primitive creation)
-  done, t0 = 0, time.perf_counter()
-  while True:
-    one_batch()
-    done += raw.shape[0]
-    el = time.perf_counter() - t0
-    if el >= budget_s or done >= 64:
-      break
-  return {"value": round(done / el, 3), "unit": "scans/s", "cores": cores, "kind": "port",
-          "sample": "%d synthetic %dx%d scans, batch 2, PyTorch-CPU (oneDNN) expression of the same "
-                    "graph and weights (oracle/torch_ref.py); TF2 itself is not installable here"
-                    % (done, h, w)}
+  main, done = _cpu_leg(net, mc, raw, cores, 2, 0.5 * budget_s, 64)
+  b1, done_b1 = _cpu_leg(net, mc, raw, cores, 1, 0.2 * budget_s, 32)
+  t1, done_t1 = _cpu_leg(net, mc, raw, 1, 1, 0.3 * budget_s, 8)
+  out = {"value": main, "unit": "scans/s", "cores": cores, "kind": "port",
+         "sample": "%d synthetic %dx%d scans, batch 2, PyTorch-CPU (oneDNN) expression of the same "
+                   "graph and weights (oracle/torch_ref.py); TF2 itself is not installable here"
+                   % (done, h, w),
+         "legs": {"batch1_%dthreads" % cores: {"value": b1, "scans": done_b1},
+                  "batch1_1thread": {"value": t1, "scans": done_t1}}}
+  real = os.path.join(ROOT, "tests", "golden", "model_ssv2_real_32x240.npz")
+  if model_name == "squeezesegv2" and os.path.exists(real):
+    # BASELINE.json configs[0] (C1): SqueezeSegV2 / NC 11 on real scans of the reference's
+    # dataset_samples/sample_dataset (committed as a fixture), the reference's B = 1 loop
+    import pclsegmentation_amd as P
+    from pclsegmentation_amd.nets.weights import synthetic_weights
+    mc1, m1 = P.load_model_config("squeezesegv2", "squeezesegv2")
+    net1 = TorchNet("squeezesegv2", synthetic_weights(m1.weight_spec(), 4321))
+    raw1 = np.load(real)["raw"]
+    c1, done_c1 = _cpu_leg(net1, mc1, raw1, cores, 1, 2.0, 64)
+    out["legs"]["c1_real_32x240_batch1_%dthreads" % cores] = {"value": c1, "scans": done_c1}
+  torch.set_num_threads(cores)
+  return out
 
 
 def _timed(fn, stream, steps, warmup):
@@ -160,20 +191,106 @@ def aux_rows(args):
 
 
 
+def csrc_sha():
+  """sha256 over the kernel / engine sources: ties a committed PMC traffic figure to the code it
+  was measured on (bench.py refuses to print a stale one)."""
+  import hashlib
+  h = hashlib.sha256()
+  for rel in ("pclsegmentation_amd/csrc/pclseg_kernels.h", "pclsegmentation_amd/csrc/pclseg_graph.h",
+              "pclsegmentation_amd/csrc/pclseg_api.hip", "include/pclseg.h"):
+    h.update(open(os.path.join(ROOT, rel), "rb").read())
+  return h.hexdigest()[:16]
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` (N > 1) outside torchrun: start N fresh rank processes with
+  torch.distributed.run and relay their exit status.  Nothing in THIS process has touched the GPU
+  (torch.cuda.device_count() does not initialise it), and the children are new processes, not an
+  exec of this one."""
+  import socket
+  import subprocess
+  import torch
+  with socket.socket() as so:
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  if torch.cuda.device_count() < args.gpus:
+    # fewer GPUs than ranks (e.g. a 1-GPU box): ranks share devices, and RCCL cannot put two
+    # ranks on one device -> rendezvous / broadcast over gloo.  A functional check, not a scaling run.
+    env["PCLSEG_DIST_BACKEND"] = "gloo"
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def build_engine(P, D, synthetic_weights, workload, dev_index, dev, rank, micro_batch=0, flags=0, batch=0):
+  model_name, config_name, h, w, wl_batch, pvalid, bound = WORKLOADS[workload]
+  mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=dev_index,
+                                  micro_batch=micro_batch)
+  spec = model.weight_spec()
+  weights = synthetic_weights(spec, 4321) if rank == 0 else None
+  weights = D.broadcast_weights(spec, weights, src=0, device=dev)   # one RCCL broadcast over xGMI
+  model.set_weights(weights)
+  return mc, model, model.engine(h, w, flags), weights, (batch or wl_batch)
+
+
+def time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence):
+  """-> (wall seconds, device milliseconds) of `steps` forward_raw calls, fenced on both sides."""
+  def step():
+    eng.forward_raw(scans, batch, preds, None, None, None, mem=E.MEM_DEVICE)
+  for _ in range(warmup):
+    step()
+  fence()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record(stream)
+  for _ in range(steps):
+    step()
+  ev1.record(stream)
+  fence()
+  return time.perf_counter() - t0, ev0.elapsed_time(ev1)      # HIP events on the engine's stream
+
+
+def roofline_of(bound, scans_per_s_dev, info):
+  alg_bytes, alg_flops = info["alg_bytes_per_scan"], 2 * info["alg_macs_per_scan"]
+  hbm_gbs = scans_per_s_dev * alg_bytes / 1e9
+  mfma_tf = scans_per_s_dev * alg_flops / 1e12
+  if bound == "hbm":
+    roof = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None}
+  else:
+    # useful (algorithmic) FLOP/s against the dense f16 MFMA peak divided by the 3 products the
+    # split-f16 arithmetic spends per multiply-accumulate
+    peak = F16_MFMA_PEAK_TF / 3.0
+    roof = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(mfma_tf / peak, 4), "traffic": None}
+  roof["kernel"] = "all kernels of one forward step (HIP events on the engine stream)"
+  roof["alg_bytes_per_scan"] = alg_bytes
+  roof["alg_flops_per_scan"] = alg_flops
+  roof["other"] = {"hbm_GBs": round(hbm_gbs, 1), "alg_TFLOPs": round(mfma_tf, 2),
+                   "frac_of_f16_mfma_peak_div3": round(mfma_tf / (F16_MFMA_PEAK_TF / 3.0), 4),
+                   "frac_of_f32_mfma_peak": round(mfma_tf / F32_MFMA_PEAK_TF, 4)}
+  return roof
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=10)
-  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--steps", type=int, default=100)
+  ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--workload", default="ssv2_64x2048", choices=sorted(WORKLOADS))
   ap.add_argument("--batch", type=int, default=0, help="scans per GPU per step (0 = workload default)")
   ap.add_argument("--micro-batch", type=int, default=0)
-  ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
-  ap.add_argument("--host-io", action="store_true", help="also time the step with host buffers (PCIe-inclusive)")
+  ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget; 0 disables")
+  ap.add_argument("--no-secondary", action="store_true",
+                  help="skip the secondary rows (Darknet workloads, exact-f32, host boundary)")
   ap.add_argument("--aux", action="store_true", help="measure the projection / confusion-matrix rows instead")
   args = ap.parse_args()
   if args.aux:
     return aux_rows(args)
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    raise SystemExit(self_launch(args))
 
   import torch
   import pclsegmentation_amd as P
@@ -184,33 +301,13 @@ def main():
 
   rank, local_rank, world = D.init_process_group()
   if world != args.gpus:
-    raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
   dev_index = local_rank % torch.cuda.device_count()   # identity on a node with one GPU per rank
   torch.cuda.set_device(dev_index)
   dev = torch.device("cuda", dev_index)
-
-  model_name, config_name, h, w, batch, pvalid, bound = WORKLOADS[args.workload]
-  if args.batch:
-    batch = args.batch
-  mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=dev_index,
-                                  micro_batch=args.micro_batch)
-  spec = model.weight_spec()
-  weights = synthetic_weights(spec, 4321) if rank == 0 else None
-  weights = D.broadcast_weights(spec, weights, src=0, device=dev)   # one RCCL broadcast over xGMI
-  model.set_weights(weights)
-  eng = model.engine(h, w)
   stream = torch.cuda.current_stream(dev)
-  eng.set_stream(stream.cuda_stream)
-  info = E.plan(eng.desc)
-
-  scans = torch.from_numpy(synthetic_scans(batch, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid,
-                                           seed=1234 + rank)).to(dev)
-  preds = torch.empty((batch, h, w), dtype=torch.int32, device=dev)
-
-  def step():
-    eng.forward_raw(scans, batch, preds, None, None, None, mem=E.MEM_DEVICE)
 
   def fence():
     torch.cuda.synchronize(dev)
@@ -218,78 +315,117 @@ def main():
       torch.distributed.barrier()
     torch.cuda.synchronize(dev)
 
-  for _ in range(args.warmup):
-    step()
-  fence()
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record(stream)
-  for _ in range(args.steps):
-    step()
-  ev1.record(stream)
-  fence()
-  elapsed = time.perf_counter() - t0
-  dev_ms = ev0.elapsed_time(ev1)      # HIP events on the engine's stream
-  if world > 1:
-    t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed, dev_ms = float(t[0]), float(t[1])
+  def run_workload(workload, steps, warmup, flags=0, batch=0):
+    """Build the engine of `workload`, time `steps` steps; -> dict for rank 0 (None elsewhere)."""
+    model_name, config_name, h, w, _, pvalid, bound = WORKLOADS[workload]
+    mc, model, eng, weights, batch = build_engine(P, D, synthetic_weights, workload, dev_index, dev, rank,
+                                                  args.micro_batch, flags, batch)
+    eng.set_stream(stream.cuda_stream)
+    info = E.plan(eng.desc)
+    scans = torch.from_numpy(synthetic_scans(batch, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid,
+                                             seed=1234 + rank)).to(dev)
+    preds = torch.empty((batch, h, w), dtype=torch.int32, device=dev)
+    elapsed, dev_ms = time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence)
+    eng.sync()   # also reports a split-f16 range overflow (PCLSEG_ERR_RANGE) instead of timing garbage
+    if world > 1:
+      t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+      elapsed, dev_ms = float(t[0]), float(t[1])
+    res = {"mc": mc, "model": model, "eng": eng, "weights": weights, "info": info, "batch": batch,
+           "scans": scans, "preds": preds, "elapsed": elapsed, "dev_ms": dev_ms, "h": h, "w": w,
+           "pvalid": pvalid, "bound": bound, "model_name": model_name,
+           "scans_per_s": world * batch * steps / elapsed,
+           "dev_scans_per_s": batch * steps / (dev_ms * 1e-3)}
+    return res
 
+  r = run_workload(args.workload, args.steps, args.warmup, batch=args.batch)
   if rank == 0:
-    scans_per_s = world * batch * args.steps / elapsed
-    alg_bytes = info["alg_bytes_per_scan"]
-    alg_flops = 2 * info["alg_macs_per_scan"]
-    # roofline over the kernels of one step, per GPU, from the HIP-event time
-    dev_scans_per_s = batch * args.steps / (dev_ms * 1e-3)
-    hbm_gbs = dev_scans_per_s * alg_bytes / 1e9
-    mfma_tf = dev_scans_per_s * alg_flops / 1e12
-    if bound == "hbm":
-      roof = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None}
-    else:
-      # useful (algorithmic) FLOP/s against the dense f16 MFMA peak divided by the 3 products the
-      # split-f16 arithmetic spends per multiply-accumulate
-      peak = F16_MFMA_PEAK_TF / 3.0
-      roof = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": round(peak, 1),
-              "unit": "TFLOP/s", "frac": round(mfma_tf / peak, 4), "traffic": None}
-    # measured HBM-side bytes (PMC passes of this same command, committed under profiles/)
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    roof = roofline_of(r["bound"], r["dev_scans_per_s"], r["info"])
+    # measured HBM-side bytes (PMC passes of this same command, committed under profiles/): only
+    # quoted when the committed figure was measured on exactly these kernel sources
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if args.workload == "ssv2_64x2048" and os.path.exists(tpath):
       t = json.load(open(tpath))
-      roof["traffic"] = int(t["hbm_bytes_per_scan"])
-      roof["traffic_unit"] = "HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), profiles/r01_traffic.json"
-    roof["kernel"] = "all kernels of one forward step (HIP events on the engine stream)"
-    roof["alg_bytes_per_scan"] = alg_bytes
-    roof["alg_flops_per_scan"] = alg_flops
-    roof["other"] = {"hbm_GBs": round(hbm_gbs, 1), "alg_TFLOPs": round(mfma_tf, 2),
-                     "frac_of_f16_mfma_peak_div3": round(mfma_tf / (F16_MFMA_PEAK_TF / 3.0), 4),
-                     "frac_of_f32_mfma_peak": round(mfma_tf / F32_MFMA_PEAK_TF, 4)}
+      if t.get("csrc_sha") == csrc_sha():
+        roof["traffic"] = int(t["hbm_bytes_per_scan"])
+        roof["traffic_unit"] = ("HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
+                                "profiles/r02_traffic.json, csrc sha %s" % t["csrc_sha"])
+      else:
+        roof["traffic_note"] = ("profiles/r02_traffic.json was measured on csrc sha %s, this build is %s: "
+                                "stale figure withheld" % (t.get("csrc_sha"), csrc_sha()))
+    mc = r["mc"]
     out = {
       "metric": "LiDAR scans/sec (64x2048) SqueezeSegV2 inference" if args.workload == "ssv2_64x2048"
                 else "LiDAR scans/sec %s inference" % args.workload,
-      "value": round(scans_per_s, 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
-      "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-      "data": "synthetic",
-      "config": {"workload": args.workload, "model": model_name, "shape": [h, w],
-                 "num_class": mc.NUM_CLASS, "batch_per_gpu": batch, "global_batch": batch * world,
-                 "math": "f16x3 products, f32 accumulate", "micro_batch": info["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")), "parallelism": "batch-sharded x%d" % world},
+      "value": round(r["scans_per_s"], 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": round(1e3 * r["elapsed"] / args.steps, 3),
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "f32 (f16x3 products)", "data": "synthetic",
+      "config": {"workload": args.workload, "model": r["model_name"], "shape": [r["h"], r["w"]],
+                 "num_class": mc.NUM_CLASS, "batch_per_gpu": r["batch"], "global_batch": r["batch"] * world,
+                 "math": "storage, accumulation and outputs float32; products on split-f16 operands "
+                         "(hi*hi + hi*lo + lo*hi, 22-bit) on v_mfma_f32_16x16x32_f16",
+                 "micro_batch": r["info"]["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")),
+                 "parallelism": "batch-sharded x%d" % world},
       "roofline": roof,
     }
-    if world == 1 and args.host_io:
-      # informational only (never `value`): the same step when the boundary hands over HOST
-      # buffers, i.e. raw scans cross PCIe in and int32 predictions cross it back
-      h_scans = scans.cpu().numpy()
-      h_preds = np.empty((batch, h, w), np.int32)
-      for _ in range(2):
-        eng.forward_raw(h_scans, batch, h_preds, None, None, None, mem=E.MEM_HOST)
-      t1 = time.perf_counter()
-      for _ in range(args.steps):
-        eng.forward_raw(h_scans, batch, h_preds, None, None, None, mem=E.MEM_HOST)
-      out["host_boundary"] = {"value": round(batch * args.steps / (time.perf_counter() - t1), 1), "unit": "scans/s",
-                              "note": "pageable host buffers in and out over PCIe, synchronous call"}
+    if os.environ.get("PCLSEG_DIST_BACKEND") == "gloo" and world > 1:
+      out["config"]["note"] = "ranks share GPUs (fewer devices than ranks): functional check, not a scaling run"
+  if world == 1 and not args.no_secondary:
+    batch, h, w = r["batch"], r["h"], r["w"]
+    # ---- the same step when the boundary hands over HOST buffers (never `value`): raw scans cross
+    # PCIe in, int32 predictions cross it back, page-locked buffers, per-micro-batch copies on the
+    # lane streams overlapped with the kernels of the other lanes
+    eng = r["eng"]
+    h_scans = torch.empty((batch, h, w, 5), dtype=torch.float32).pin_memory()
+    h_scans.copy_(r["scans"].cpu())
+    h_preds = torch.empty((batch, h, w), dtype=torch.int32).pin_memory()
+    hs = min(args.steps, 30)
+    for _ in range(3):
+      eng.forward_raw(h_scans, batch, h_preds, None, None, None, mem=E.MEM_HOST)
+    t1 = time.perf_counter()
+    for _ in range(hs):
+      eng.forward_raw(h_scans, batch, h_preds, None, None, None, mem=E.MEM_HOST)
+    pinned = batch * hs / (time.perf_counter() - t1)
+    same = bool(torch.equal(h_preds, r["preds"].cpu()))
+    p_scans, p_preds = h_scans.numpy().copy(), np.empty((batch, h, w), np.int32)   # pageable
+    for _ in range(2):
+      eng.forward_raw(p_scans, batch, p_preds, None, None, None, mem=E.MEM_HOST)
+    t1 = time.perf_counter()
+    for _ in range(hs):
+      eng.forward_raw(p_scans, batch, p_preds, None, None, None, mem=E.MEM_HOST)
+    pageable = batch * hs / (time.perf_counter() - t1)
+    out["host_boundary"] = {
+      "value": round(pinned, 1), "unit": "scans/s", "frac_of_device_resident": round(pinned / r["scans_per_s"], 3),
+      "note": "page-locked host buffers in and out over PCIe, synchronous call, copies per micro-batch on the "
+              "lane streams overlapped with compute; predictions identical to the device-resident run: %s" % same,
+      "pageable": {"value": round(pageable, 1), "note": "pageable NumPy buffers through the library's pinned bounce slabs"}}
+    # ---- the headline workload with exact float32 products (PCLSEG_FLAG_EXACT_F32)
+    del eng
+    r["model"]._drop_engines()
+    x = run_workload(args.workload, 5, 2, flags=E.FLAG_EXACT_F32, batch=args.batch)
+    out["exact_f32"] = {"value": round(x["scans_per_s"], 1), "unit": "scans/s",
+                        "ms_per_step": round(1e3 * x["elapsed"] / 5, 3),
+                        "note": "same workload, every product on v_mfma_f32_16x16x4_f32 (bit-exact float32)"}
+    x["model"]._drop_engines()
+    del x
+    # ---- the other single-GPU configurations of BASELINE.json (parity-tested in tests/, timed here
+    # for a few steps; their bound is the matrix cores)
+    out["secondary"] = []
+    for wl, st, wu in (("darknet53_64x2048", 6, 2), ("darknet21_32x1024", 10, 3)):
+      if wl == args.workload:
+        continue
+      y = run_workload(wl, st, wu)
+      out["secondary"].append({
+        "workload": wl, "value": round(y["scans_per_s"], 1), "unit": "scans/s", "steps": st, "warmup": wu,
+        "batch": y["batch"], "ms_per_step": round(1e3 * y["elapsed"] / st, 3),
+        "roofline": roofline_of(y["bound"], y["dev_scans_per_s"], y["info"])})
+      y["model"]._drop_engines()
+      del y
+  if rank == 0:
     if world == 1 and args.cpu_seconds > 0:
-      out["cpu_baseline"] = cpu_baseline(model_name, mc, weights, h, w, pvalid, args.cpu_seconds)
+      out["cpu_baseline"] = cpu_baseline(r["model_name"], r["mc"], r["weights"], r["h"], r["w"], r["pvalid"],
+                                         args.cpu_seconds)
     print(json.dumps(out), flush=True)
   if world > 1:
     torch.distributed.barrier()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PCLSEG_VERSION 100 /* major*10000 + minor*100 + patch */
+#define PCLSEG_VERSION 200 /* major*10000 + minor*100 + patch */
 
 typedef struct pclseg_handle pclseg_handle;
 
@@ -42,7 +42,9 @@ typedef enum pclseg_status {
   PCLSEG_ERR_MISSING_WEIGHT = -3, /* finalize with an unset tensor / unknown Keras path    */
   PCLSEG_ERR_HIP = -4,            /* HIP runtime error (incl. "no GPU")                     */
   PCLSEG_ERR_OOM = -5,
-  PCLSEG_ERR_STATE = -6           /* forward before finalize, set_weight after finalize     */
+  PCLSEG_ERR_STATE = -6,          /* forward before finalize, set_weight after finalize     */
+  PCLSEG_ERR_RANGE = -7           /* split-f16 mode: an activation reached |v| >= 65504 (f16 range);
+                                     the outputs of the offending call are not valid            */
 } pclseg_status;
 
 /* model_map keys of the reference (utils/args_loader.py:36-40); darknet21/53 differ only in
@@ -62,11 +64,19 @@ typedef enum pclseg_mem { PCLSEG_MEM_HOST = 0, PCLSEG_MEM_DEVICE = 1 } pclseg_me
                                            (bit-exact float32 products) instead of the default
                                            split-f16 products (see pclseg_math) */
 
+#define PCLSEG_FLAG_RANGE_FALLBACK 4u   /* split-f16 mode: keep the exact-f32 weight fragments resident
+                                           too and, when the range guard fires, transparently re-run
+                                           the offending call with exact float32 products instead of
+                                           returning PCLSEG_ERR_RANGE */
+
 /* Arithmetic of the convolutions.  Activations, accumulation and all outputs are float32 in
  * both modes.
  *   PCLSEG_MATH_F16X3: each float32 operand v is split hi = f16(v), lo = f16(v - hi) and a
  *     product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (22-bit operands; logits
- *     within ~1e-5 of the float64 oracle).  Default.  Requires |activation| < 65504.
+ *     within ~1e-5 of the float64 oracle).  Default.  Requires |activation| < 65504: every kernel that
+ *     splits a value checks it, a violation sets a sticky flag on the device and the call that
+ *     observes it (a PCLSEG_MEM_HOST forward, or pclseg_sync after PCLSEG_MEM_DEVICE forwards)
+ *     returns PCLSEG_ERR_RANGE — or repairs the call, see PCLSEG_FLAG_RANGE_FALLBACK.
  *   PCLSEG_MATH_F32: v_mfma_f32_16x16x4_f32, exact float32 products. */
 typedef enum pclseg_math { PCLSEG_MATH_F16X3 = 0, PCLSEG_MATH_F32 = 1 } pclseg_math;
 
@@ -134,7 +144,17 @@ int pclseg_finalize(pclseg_handle* h);
 
 /* Use `hip_stream` (a hipStream_t) for all subsequent work; NULL = the legacy default stream. */
 int pclseg_set_stream(pclseg_handle* h, void* hip_stream);
+/* Wait for the handle's stream.  Returns PCLSEG_ERR_RANGE if a split-f16 kernel since the last
+ * check saw an out-of-range activation (with PCLSEG_FLAG_RANGE_FALLBACK: re-runs the last
+ * PCLSEG_MEM_DEVICE forward call in exact float32 and returns PCLSEG_OK). */
 int pclseg_sync(pclseg_handle* h);
+
+/* Page-locked host memory for the PCLSEG_MEM_HOST boundary (the reference hands NumPy arrays to
+ * Keras, inference.py:71-75).  Buffers from here (or any hipHostMalloc / hipHostRegister /
+ * torch pin_memory buffer) are DMA'd directly and overlapped with compute; pageable buffers are
+ * accepted too and go through the library's own pinned bounce buffers. */
+void* pclseg_host_alloc(size_t bytes);
+int pclseg_host_free(void* p);
 
 /* The reference-shaped call: model([lidar, mask]) -> (probabilities, predictions)
  * (nets/SegmentationNetwork.py:55-69, nets/SqueezeSegV2.py:285-325, nets/Darknet.py:279-314).

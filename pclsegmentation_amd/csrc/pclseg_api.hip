@@ -54,13 +54,33 @@ struct pclseg_handle {
   hipStream_t lane_stream[kMaxLanes] = {nullptr};
   hipEvent_t ev_in = nullptr, ev_lane[kMaxLanes] = {nullptr};
   float* d_arena = nullptr;   // arena of the lane that ran the LAST micro-batch (debug reads)
-  // host-mode staging (grown on demand)
-  void* d_stage_in = nullptr;   size_t stage_in_bytes = 0;
-  uint8_t* d_stage_mask = nullptr; size_t stage_mask_bytes = 0;
-  int32_t* d_stage_preds = nullptr; size_t stage_preds_bytes = 0;
-  float* d_stage_probs = nullptr; size_t stage_probs_bytes = 0;
-  float* d_stage_logits = nullptr; size_t stage_logits_bytes = 0;
+  // host-mode staging (grown on demand): per-lane device slabs of one micro-batch, a per-lane
+  // pinned bounce slab for pageable inputs, full-size pinned bounce buffers for pageable outputs
+  struct HostLane {
+    void* d_in = nullptr; size_t in_bytes = 0;
+    uint8_t* d_maskin = nullptr; size_t maskin_bytes = 0;
+    int32_t* d_preds = nullptr; size_t preds_bytes = 0;
+    float* d_probs = nullptr; size_t probs_bytes = 0;
+    float* d_logits = nullptr; size_t logits_bytes = 0;
+    void* p_in = nullptr; size_t p_in_bytes = 0;
+    void* p_mask = nullptr; size_t p_mask_bytes = 0;
+    hipEvent_t ev_bounce = nullptr; bool bounce_busy = false;
+  } hl[kMaxLanes];
+  int32_t* p_preds = nullptr; size_t p_preds_bytes = 0;
+  float* p_probs = nullptr; size_t p_probs_bytes = 0;
+  float* p_logits = nullptr; size_t p_logits_bytes = 0;
+  uint8_t* p_mask = nullptr; size_t p_mask_bytes = 0;
   int last_count = 0;  // scans held by the arena after the last forward
+  bool last_exact = false;  // arithmetic of the last sweep (decides how debug reads decode tensors)
+  // split-f16 range guard: device word OR-ed by any kernel that split a value with |v| >= 65504
+  unsigned* d_range = nullptr;
+  unsigned* h_range = nullptr;   // pinned host mirror
+  bool fallback = false;         // PCLSEG_FLAG_RANGE_FALLBACK: both weight sets resident
+  struct LastCall {              // what pclseg_sync re-runs in exact mode when the guard fired
+    bool valid = false;
+    const float* input = nullptr; bool raw = false; const uint8_t* mask_in = nullptr; int n = 0;
+    int32_t* preds = nullptr; float* probs = nullptr; float* logits = nullptr; uint8_t* mask_out = nullptr;
+  } last;
   std::string err;
 };
 
@@ -71,6 +91,17 @@ int fail(pclseg_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
   return code;
 }
+
+// Restores the caller's current HIP device on every exit path (a process may hold engines on
+// several GPUs, and torch's current device must not change behind its back).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 #define HIP_TRY(h, expr)                                                                   \
   do {                                                                                     \
@@ -162,13 +193,19 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 }
 
 // ---- launch helpers -------------------------------------------------------------------------
-template <int MTW, int NTW, int WN, bool HEAD, bool F16>
+template <int MTW, int NTW, int WN, bool HEAD, bool F16, bool PAIR = false, int NW = 4>
 hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
 #define PCLSEG_GO(EPI_) \
-  hipLaunchKernelGGL((conv_kernel<MTW, NTW, WN, HEAD, F16, EPI_>), grid, dim3(kConvThreads), lds, s, a)
+  hipLaunchKernelGGL((conv_kernel<MTW, NTW, WN, HEAD, F16, EPI_, PAIR, NW>), grid, dim3(NW * 64), lds, s, a)
   if constexpr (HEAD) { PCLSEG_GO(0); }
   else if constexpr (!F16) { PCLSEG_GO(4); }  // exact mode: one catch-all instantiation
-  else {
+  else if constexpr (PAIR) {                  // FIRE expand pairs: plain, + skip add, + fused skip branch
+    switch (epi) {
+      case 0: PCLSEG_GO(0); break;
+      case 1: PCLSEG_GO(1); break;
+      default: return hipErrorInvalidValue;
+    }
+  } else {
     switch (epi) {
       case 0: PCLSEG_GO(0); break;
       case 1: PCLSEG_GO(1); break;
@@ -196,10 +233,38 @@ hipError_t launch_conv_cfg(int mtw, int ntw, int wn, int epi, dim3 grid, size_t 
   return hipErrorInvalidValue;
 }
 
+// merged FIRE expand pair (split-f16 mode): the block shapes the reference's FIRE sizes use
+// (pclseg_graph.h: pair_geometry); (mtw, ntw, wn, nw)
+#define PCLSEG_PAIR_CFGS(X) X(4, 2, 2, 4) X(4, 2, 1, 4) X(8, 2, 8, 8) X(4, 3, 4, 8) X(4, 2, 4, 8) X(4, 2, 2, 8)
+inline bool pair_cfg_ok(const Op& op) {
+  if (op.sub[0].nctp != op.sub[1].nctp || op.ck16 < op.cin_t) return false;
+#define PCLSEG_X(M_, N_, W_, NW_) if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == NW_) return true;
+  PCLSEG_PAIR_CFGS(PCLSEG_X)
+#undef PCLSEG_X
+  return false;
+}
+hipError_t launch_conv_pair(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+#define PCLSEG_X(M_, N_, W_, NW_) \
+  if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == NW_) \
+    return launch_conv_epi<M_, N_, W_, false, true, true, NW_>(epi, grid, lds, s, a);
+  PCLSEG_PAIR_CFGS(PCLSEG_X)
+#undef PCLSEG_X
+  return hipErrorInvalidValue;
+}
+
 // Fill the geometry of `a` (tensor pointers already set) from `op` and launch.
 // w32 / w16 / bias are the bases the sub-op offsets are relative to.
-hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const float* w32,
+hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const float* w32,
                        const _Float16* w16, const float* bias, bool exact, hipStream_t s) {
+  Op op = op_in;
+  if (exact && op.nw != 4) {
+    // exact-f32 sweep of a graph planned for split-f16 (PCLSEG_FLAG_RANGE_FALLBACK): the 8-wave
+    // block shapes exist only for the split-f16 kernels; any 4-wave shape whose cout group divides
+    // the packed tile count reads the same fragments
+    op.nw = 4; op.mtw = 4; op.ntw = 2; op.wn = 2;
+    op.ck32 = 32;
+    while (op.ck32 > 16 && lds_bytes_f32(op, op.ck32) > 64 * 1024) op.ck32 /= 2;
+  }
   a.Cin = op.cin_t;
   a.res1_mul = op.res1_mul ? 1 : 0;
   a.nsub = op.nsub;
@@ -241,7 +306,7 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   a.tilesW = (a.Wconv + a.SEGW * 16 - 1) / (a.SEGW * 16);
   static const int use_direct = getenv("PCLSEG_DIRECT1X1") ? atoi(getenv("PCLSEG_DIRECT1X1")) : 1;
   if (use_direct && !exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.cin_t % 8 == 0 &&
-      op.ck16 >= 32 && !a.skx && !a.res2 && op.sub[0].nctp <= 4) {  // squeeze-like: few couts
+      op.ck16 >= 32 && !a.skx && !a.res2 && !a.in_s16 && op.sub[0].nctp <= 4) {  // squeeze-like: few couts
     // LDS-free streaming GEMM; every wave owns mtw*16 pixels x ntw*16 couts
     // one block column covers ALL couts (nctp <= 4 tiles), so the input is read exactly once
     const int ntw = op.sub[0].nctp;
@@ -280,8 +345,17 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
 #undef PCLSEG_D
     return hipGetLastError();
   }
-  const size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
+  size_t lds = (size_t)(exact ? lds_bytes_f32(op, op.ck32) : lds_bytes_f16(op, op.ck16));
+  lds = (lds + 15) & ~(size_t)15;
+  a.skw_lds_off = (int)lds;
+  if (a.skx) lds += (size_t)9 * a.out_C * sizeof(float);   // fused skip branch weights behind the patch
   if (lds > 64 * 1024) return hipErrorInvalidValue;
+  // (the fused-skip-branch epilogue of fire13 needs more registers than the merged kernel has left)
+  const bool pair = !exact && op.pair && pair_cfg_ok(op) && !a.skx && !a.res2;
+  if (pair) {  // one block = cout group of the 3x3 half + the same group of the 1x1 half
+    ny = a.sub[1].ny;
+    a.ny = ny;
+  }
   {
     // A layer whose packed weights fit an XCD's 4 MB L2 keeps them there under any order, so the
     // order is spent on the input patches (tile-major).  Darknet's deep layers (up to 19 MB of
@@ -295,6 +369,7 @@ hipError_t launch_conv(const Op& op, int N, int H, int Win, ConvArgs a, const fl
   }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
+  if (pair) return launch_conv_pair(op, epi, grid, lds, s, a);
   if (op.kind == OP_HEAD)
     return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
                  : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);
@@ -350,7 +425,7 @@ int ensure(pclseg_handle* h, void** p, size_t* have, size_t need) {
 
 // One sweep of the network over `cnt` scans already present in the arena's input tensor.
 int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* preds, float* probs,
-            float* logits) {
+            float* logits, bool exact) {
   const Graph& g = h->g;
   float* const arena = h->d_arena_lane[lane];
   const hipStream_t stream = h->nlanes > 1 ? h->lane_stream[lane] : h->stream;
@@ -375,6 +450,8 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = in;
+    a.in_s16 = (!exact && ti.fmt == FMT_S16) ? 1 : 0;
+    a.range_flag = exact ? nullptr : h->d_range;
     if (op.kind == OP_HEAD) {
       a.mask = mask;
       a.preds = preds;
@@ -385,14 +462,215 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
       const TensorInfo& to = g.tensors[op.out];
       a.out = arena + to.offset;
       a.out_C = to.C;
+      a.out_s16 = (!exact && to.fmt == FMT_S16) ? 1 : 0;
       if (op.res1 >= 0) { a.res1 = arena + g.tensors[op.res1].offset; a.res1_C = g.tensors[op.res1].C; }
       if (op.res2 >= 0) { a.res2 = arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
       if (op.sk_in >= 0) { a.skx = arena + g.tensors[op.sk_in].offset; a.skw = h->d_bias + op.sk.b_off; }
     }
-    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, h->exact, stream));
+    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream));
   }
   return PCLSEG_OK;
 }
+
+// Is `p` page-locked host memory (hipHostMalloc / hipHostRegister / torch pin_memory)?  Only then is
+// hipMemcpyAsync a true DMA that returns at once; pageable memory goes through a bounce buffer.
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  const hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
+// Fence the lane streams into the caller's stream (also on error paths: nothing may still be
+// running on a side stream when control returns to the caller).
+int join_lanes(pclseg_handle* h) {
+  if (h->nlanes <= 1) return PCLSEG_OK;
+  for (int l = 0; l < h->nlanes; ++l) {
+    HIP_TRY(h, hipEventRecord(h->ev_lane[l], h->lane_stream[l]));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_lane[l], 0));
+  }
+  return PCLSEG_OK;
+}
+void drain_after_error(pclseg_handle* h) {
+  for (int l = 0; l < h->nlanes; ++l)
+    if (h->lane_stream[l]) (void)hipStreamSynchronize(h->lane_stream[l]);
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipGetLastError();
+}
+
+// Host-boundary staging of one lane (PCLSEG_MEM_HOST).  Device slabs hold one micro-batch; the
+// pinned bounce slab is only used when the caller's input is pageable memory.
+int ensure_host_lane(pclseg_handle* h, int l, size_t in_bytes, size_t px, int NC, bool want_probs, bool want_logits) {
+  pclseg_handle::HostLane& L = h->hl[l];
+  int rc;
+  if ((rc = ensure(h, (void**)&L.d_in, &L.in_bytes, in_bytes))) return rc;
+  if ((rc = ensure(h, (void**)&L.d_maskin, &L.maskin_bytes, px))) return rc;
+  if ((rc = ensure(h, (void**)&L.d_preds, &L.preds_bytes, px * sizeof(int32_t)))) return rc;
+  if (want_probs && (rc = ensure(h, (void**)&L.d_probs, &L.probs_bytes, px * NC * sizeof(float)))) return rc;
+  if (want_logits && (rc = ensure(h, (void**)&L.d_logits, &L.logits_bytes, px * NC * sizeof(float)))) return rc;
+  return PCLSEG_OK;
+}
+int ensure_pinned(pclseg_handle* h, void** p, size_t* have, size_t need) {
+  if (*have >= need) return PCLSEG_OK;
+  if (*p) HIP_TRY(h, hipHostFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(h, hipHostMalloc(p, need, hipHostMallocDefault));
+  *have = need;
+  return PCLSEG_OK;
+}
+
+// The sweep of one call: micro-batches dealt round-robin to the lanes.
+//   PCLSEG_MEM_DEVICE: pointers are device memory; asynchronous on the handle's stream.
+//   PCLSEG_MEM_HOST  : every micro-batch's input crosses PCIe on ITS LANE's stream (H2D of
+//     micro-batch k+1 runs beside the kernels of k on another lane and the D2H of k-1), results
+//     return the same way; page-locked caller buffers are DMA'd directly, pageable ones go through
+//     pinned bounce buffers (input: per-lane slab, copied by the CPU while the GPU works on earlier
+//     micro-batches; outputs: one full-size pinned buffer, copied out after the final fence).
+int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in, int n, int32_t* preds,
+          float* probs, float* logits, uint8_t* mask_out, int mem, bool exact) {
+  const Graph& g = h->g;
+  const size_t HW = (size_t)g.desc.height * g.desc.width;
+  const int NC = g.desc.num_class;
+  const int cin = raw ? 5 : 6;
+  const bool host = mem == PCLSEG_MEM_HOST;
+  const bool multi = h->nlanes > 1;
+
+  // Micro-batches: at most g.micro_batch scans each, their number rounded up to a multiple of the
+  // lane count and the scans spread evenly, so every lane gets the same work (32 scans, 3 lanes:
+  // 4,4,4,4,4,3,3,3,3 instead of eight 4s dealt 3/3/2).
+  int nmb = (n + g.micro_batch - 1) / g.micro_batch;
+  if (multi && nmb > 1) nmb = std::min(n, ((nmb + h->nlanes - 1) / h->nlanes) * h->nlanes);
+  const int mb_lo = n / nmb, mb_extra = n % nmb;  // the first mb_extra micro-batches take one more
+  const int mb_max = mb_lo + (mb_extra ? 1 : 0);
+
+  bool in_pinned = false, mask_pinned = false;
+  int32_t* o_preds = preds; float* o_probs = probs; float* o_logits = logits; uint8_t* o_mask = mask_out;
+  if (host) {
+    int rc;
+    for (int l = 0; l < std::min(h->nlanes, nmb); ++l)
+      if ((rc = ensure_host_lane(h, l, (size_t)mb_max * HW * cin * sizeof(float), (size_t)mb_max * HW, NC,
+                                 probs != nullptr, logits != nullptr))) return rc;
+    in_pinned = is_pinned_host(input);
+    mask_pinned = raw || is_pinned_host(mask_in);
+    if (!in_pinned || !mask_pinned)
+      for (int l = 0; l < std::min(h->nlanes, nmb); ++l) {
+        pclseg_handle::HostLane& L = h->hl[l];
+        if (!in_pinned && (rc = ensure_pinned(h, (void**)&L.p_in, &L.p_in_bytes, (size_t)mb_max * HW * cin * sizeof(float)))) return rc;
+        if (!mask_pinned && (rc = ensure_pinned(h, (void**)&L.p_mask, &L.p_mask_bytes, (size_t)mb_max * HW))) return rc;
+        if (!L.ev_bounce) HIP_TRY(h, hipEventCreateWithFlags(&L.ev_bounce, hipEventDisableTiming));
+        L.bounce_busy = false;
+      }
+    // pageable outputs: full-size pinned bounce, copied out after the fence
+    if (!is_pinned_host(preds)) {
+      if ((rc = ensure_pinned(h, (void**)&h->p_preds, &h->p_preds_bytes, (size_t)n * HW * sizeof(int32_t)))) return rc;
+      o_preds = h->p_preds;
+    }
+    if (probs && !is_pinned_host(probs)) {
+      if ((rc = ensure_pinned(h, (void**)&h->p_probs, &h->p_probs_bytes, (size_t)n * HW * NC * sizeof(float)))) return rc;
+      o_probs = h->p_probs;
+    }
+    if (logits && !is_pinned_host(logits)) {
+      if ((rc = ensure_pinned(h, (void**)&h->p_logits, &h->p_logits_bytes, (size_t)n * HW * NC * sizeof(float)))) return rc;
+      o_logits = h->p_logits;
+    }
+    if (mask_out && !is_pinned_host(mask_out)) {
+      if ((rc = ensure_pinned(h, (void**)&h->p_mask, &h->p_mask_bytes, (size_t)n * HW))) return rc;
+      o_mask = h->p_mask;
+    }
+  }
+
+  NormArgs na;
+  for (int i = 0; i < 5; ++i) { na.mean[i] = g.desc.mean[i]; na.std[i] = g.desc.std[i]; }
+  if (multi) {  // lanes start after everything already queued on the caller's stream (inputs)
+    HIP_TRY(h, hipEventRecord(h->ev_in, h->stream));
+    for (int l = 0; l < h->nlanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_in, 0));
+  }
+  int s0 = 0;
+  for (int mbi = 0; mbi < nmb; ++mbi) {
+    const int cnt = mb_lo + (mbi < mb_extra ? 1 : 0);
+    const size_t P = (size_t)cnt * HW;
+    const int lane = mbi % h->nlanes;
+    const hipStream_t stream = multi ? h->lane_stream[lane] : h->stream;
+    pclseg_handle::HostLane& L = h->hl[lane];
+    float* d_lidar8 = h->d_arena_lane[lane] + g.tensors[g.t_input].offset;
+    const float* d_in = input + (size_t)s0 * HW * cin;
+    const uint8_t* d_mask_in = mask_in ? mask_in + (size_t)s0 * HW : nullptr;
+    int32_t* d_preds = preds + (size_t)s0 * HW;
+    float* d_probs = probs ? probs + (size_t)s0 * HW * NC : nullptr;
+    float* d_logits = logits ? logits + (size_t)s0 * HW * NC : nullptr;
+    uint8_t* d_mask_out = mask_out ? mask_out + (size_t)s0 * HW : nullptr;
+    if (host) {
+      const float* src = d_in;
+      const uint8_t* msrc = d_mask_in;
+      if (!in_pinned || !mask_pinned) {
+        // the bounce slab of this lane is free once the H2D copies of its previous micro-batch ran
+        if (L.bounce_busy) HIP_TRY(h, hipEventSynchronize(L.ev_bounce));
+        if (!in_pinned) { memcpy(L.p_in, d_in, P * cin * sizeof(float)); src = (const float*)L.p_in; }
+        if (!mask_pinned) { memcpy(L.p_mask, d_mask_in, P); msrc = (const uint8_t*)L.p_mask; }
+      }
+      HIP_TRY(h, hipMemcpyAsync(L.d_in, src, P * cin * sizeof(float), hipMemcpyHostToDevice, stream));
+      if (!raw) HIP_TRY(h, hipMemcpyAsync(L.d_maskin, msrc, P, hipMemcpyHostToDevice, stream));
+      if (!in_pinned || !mask_pinned) { HIP_TRY(h, hipEventRecord(L.ev_bounce, stream)); L.bounce_busy = true; }
+      d_in = (const float*)L.d_in;
+      d_mask_in = L.d_maskin;
+      d_preds = L.d_preds;
+      d_probs = probs ? L.d_probs : nullptr;
+      d_logits = logits ? L.d_logits : nullptr;
+      d_mask_out = nullptr;   // the lane's own mask slab, copied out below
+    }
+    const uint8_t* mask_mb;
+    if (raw) {
+      uint8_t* mdst = d_mask_out ? d_mask_out : h->d_mask_lane[lane];
+      hipLaunchKernelGGL(normalize_kernel<8>, dim3(stream_blocks(P)), dim3(256), 0, stream, d_in, d_lidar8, mdst, P, na);
+      HIP_TRY(h, hipGetLastError());
+      mask_mb = mdst;
+    } else {
+      hipLaunchKernelGGL(pad6to8_kernel, dim3(stream_blocks(P)), dim3(256), 0, stream, d_in, d_lidar8, P);
+      HIP_TRY(h, hipGetLastError());
+      mask_mb = d_mask_in;
+    }
+    int rc = run_ops(h, lane, cnt, mask_mb, d_preds, d_probs, d_logits, exact);
+    if (rc) return rc;
+    if (host) {
+      HIP_TRY(h, hipMemcpyAsync(o_preds + (size_t)s0 * HW, d_preds, P * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+      if (probs) HIP_TRY(h, hipMemcpyAsync(o_probs + (size_t)s0 * HW * NC, d_probs, P * NC * sizeof(float), hipMemcpyDeviceToHost, stream));
+      if (logits) HIP_TRY(h, hipMemcpyAsync(o_logits + (size_t)s0 * HW * NC, d_logits, P * NC * sizeof(float), hipMemcpyDeviceToHost, stream));
+      if (mask_out) HIP_TRY(h, hipMemcpyAsync(o_mask + (size_t)s0 * HW, mask_mb, P, hipMemcpyDeviceToHost, stream));
+    }
+    h->last_count = cnt;
+    h->last_exact = exact;
+    h->d_arena = h->d_arena_lane[lane];
+    s0 += cnt;
+  }
+  int rc = join_lanes(h);  // the caller's stream continues only after every lane has drained
+  if (rc) return rc;
+  if (host) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (o_preds != preds) memcpy(preds, o_preds, (size_t)n * HW * sizeof(int32_t));
+    if (probs && o_probs != probs) memcpy(probs, o_probs, (size_t)n * HW * NC * sizeof(float));
+    if (logits && o_logits != logits) memcpy(logits, o_logits, (size_t)n * HW * NC * sizeof(float));
+    if (mask_out && o_mask != mask_out) memcpy(mask_out, o_mask, (size_t)n * HW);
+  }
+  return PCLSEG_OK;
+}
+
+// Read (and clear) the sticky split-f16 range flag; the handle's stream must be idle.
+int take_range_flag(pclseg_handle* h, bool* fired) {
+  *fired = false;
+  if (h->exact || !h->d_range) return PCLSEG_OK;
+  HIP_TRY(h, hipMemcpy(h->h_range, h->d_range, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (*h->h_range) {
+    *fired = true;
+    HIP_TRY(h, hipMemset(h->d_range, 0, sizeof(unsigned)));
+  }
+  return PCLSEG_OK;
+}
+
+const char* kRangeMsg =
+    "split-f16 range exceeded: an activation reached |v| >= 65504, the results of this call are not valid; "
+    "create the handle with PCLSEG_FLAG_EXACT_F32 or PCLSEG_FLAG_RANGE_FALLBACK";
 
 int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in, int n,
                  int32_t* preds, float* probs, float* logits, uint8_t* mask_out, int mem) {
@@ -403,93 +681,23 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
   if (n <= 0) return fail(h, PCLSEG_ERR_BAD_ARG, fmt("n must be positive, got %d", n));
   if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE)
     return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
-  HIP_TRY(h, hipSetDevice(h->device));
-  const Graph& g = h->g;
-  const size_t HW = (size_t)g.desc.height * g.desc.width;
-  const int NC = g.desc.num_class;
-  const int cin = raw ? 5 : 6;
-
-  const float* d_in = input;
-  const uint8_t* d_mask_in = mask_in;
-  int32_t* d_preds = preds;
-  float* d_probs = probs;
-  float* d_logits = logits;
-  uint8_t* d_mask_out = mask_out;
-  if (mem == PCLSEG_MEM_HOST) {
-    int rc;
-    if ((rc = ensure(h, &h->d_stage_in, &h->stage_in_bytes, n * HW * cin * sizeof(float)))) return rc;
-    if ((rc = ensure(h, (void**)&h->d_stage_preds, &h->stage_preds_bytes, n * HW * sizeof(int32_t)))) return rc;
-    if (!raw || mask_out)
-      if ((rc = ensure(h, (void**)&h->d_stage_mask, &h->stage_mask_bytes, n * HW))) return rc;
-    if (probs && (rc = ensure(h, (void**)&h->d_stage_probs, &h->stage_probs_bytes, n * HW * NC * sizeof(float)))) return rc;
-    if (logits && (rc = ensure(h, (void**)&h->d_stage_logits, &h->stage_logits_bytes, n * HW * NC * sizeof(float)))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->d_stage_in, input, n * HW * cin * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    d_in = (const float*)h->d_stage_in;
-    if (!raw) {
-      HIP_TRY(h, hipMemcpyAsync(h->d_stage_mask, mask_in, n * HW, hipMemcpyHostToDevice, h->stream));
-      d_mask_in = h->d_stage_mask;
-    }
-    d_preds = h->d_stage_preds;
-    d_probs = probs ? h->d_stage_probs : nullptr;
-    d_logits = logits ? h->d_stage_logits : nullptr;
-    d_mask_out = mask_out ? h->d_stage_mask : nullptr;
+  DeviceGuard guard(h->device);
+  int rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, h->exact);
+  if (rc) { drain_after_error(h); return rc; }
+  h->last.valid = false;
+  if (mem == PCLSEG_MEM_DEVICE) {   // asynchronous: pclseg_sync reports / repairs a range overflow
+    h->last.valid = true;
+    h->last.input = input; h->last.raw = raw; h->last.mask_in = mask_in; h->last.n = n;
+    h->last.preds = preds; h->last.probs = probs; h->last.logits = logits; h->last.mask_out = mask_out;
+    return PCLSEG_OK;
   }
-
-  NormArgs na;
-  for (int i = 0; i < 5; ++i) { na.mean[i] = g.desc.mean[i]; na.std[i] = g.desc.std[i]; }
-  const bool multi = h->nlanes > 1;
-  if (multi) {  // lanes start after everything already queued on the caller's stream (inputs)
-    HIP_TRY(h, hipEventRecord(h->ev_in, h->stream));
-    for (int l = 0; l < h->nlanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_in, 0));
-  }
-  // Micro-batches: at most g.micro_batch scans each, their number rounded up to a multiple of the
-  // lane count and the scans spread evenly, so every lane gets the same work (32 scans, 3 lanes:
-  // 4,4,4,4,4,3,3,3,3 instead of eight 4s dealt 3/3/2).
-  int nmb = (n + g.micro_batch - 1) / g.micro_batch;
-  if (multi && nmb > 1) nmb = std::min(n, ((nmb + h->nlanes - 1) / h->nlanes) * h->nlanes);
-  const int mb_lo = n / nmb, mb_extra = n % nmb;  // the first mb_extra micro-batches take one more
-  int s0 = 0;
-  for (int mbi = 0; mbi < nmb; ++mbi) {
-    const int cnt = mb_lo + (mbi < mb_extra ? 1 : 0);
-    const size_t P = (size_t)cnt * HW;
-    const int lane = mbi % h->nlanes;
-    const hipStream_t stream = multi ? h->lane_stream[lane] : h->stream;
-    float* d_lidar8 = h->d_arena_lane[lane] + g.tensors[g.t_input].offset;
-    const uint8_t* mask_mb;
-    if (raw) {
-      uint8_t* mdst = d_mask_out ? d_mask_out + (size_t)s0 * HW : h->d_mask_lane[lane];
-      hipLaunchKernelGGL(normalize_kernel<8>, dim3(stream_blocks(P)), dim3(256), 0, stream,
-                         d_in + (size_t)s0 * HW * 5, d_lidar8, mdst, P, na);
-      HIP_TRY(h, hipGetLastError());
-      mask_mb = mdst;
-    } else {
-      hipLaunchKernelGGL(pad6to8_kernel, dim3(stream_blocks(P)), dim3(256), 0, stream,
-                         d_in + (size_t)s0 * HW * 6, d_lidar8, P);
-      HIP_TRY(h, hipGetLastError());
-      mask_mb = d_mask_in + (size_t)s0 * HW;
-    }
-    int rc = run_ops(h, lane, cnt, mask_mb, d_preds + (size_t)s0 * HW,
-                     d_probs ? d_probs + (size_t)s0 * HW * NC : nullptr,
-                     d_logits ? d_logits + (size_t)s0 * HW * NC : nullptr);
-    if (rc) return rc;
-    h->last_count = cnt;
-    h->d_arena = h->d_arena_lane[lane];
-    s0 += cnt;
-  }
-  if (multi) {  // the caller's stream continues only after every lane has drained
-    for (int l = 0; l < h->nlanes; ++l) {
-      HIP_TRY(h, hipEventRecord(h->ev_lane[l], h->lane_stream[l]));
-      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_lane[l], 0));
-    }
-  }
-  if (mem == PCLSEG_MEM_HOST) {
-    HIP_TRY(h, hipMemcpyAsync(preds, d_preds, n * HW * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    if (probs) HIP_TRY(h, hipMemcpyAsync(probs, d_probs, n * HW * NC * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (logits) HIP_TRY(h, hipMemcpyAsync(logits, d_logits, n * HW * NC * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (mask_out) HIP_TRY(h, hipMemcpyAsync(mask_out, d_mask_out, n * HW, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-  }
-  return PCLSEG_OK;
+  bool fired = false;
+  if ((rc = take_range_flag(h, &fired))) return rc;
+  if (!fired) return PCLSEG_OK;
+  if (!h->fallback) return fail(h, PCLSEG_ERR_RANGE, kRangeMsg);
+  rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, true);   // exact float32
+  if (rc) drain_after_error(h);
+  return rc;
 }
 
 struct DevBuf {
@@ -587,8 +795,12 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
                                     e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
   if (desc->device < 0 || desc->device >= ndev)
     return bail(PCLSEG_ERR_BAD_ARG, fmt("device %d out of range (have %d)", desc->device, ndev));
-  if ((e = hipSetDevice(desc->device)) != hipSuccess)
-    return bail(PCLSEG_ERR_HIP, fmt("hipSetDevice(%d): %s", desc->device, hipGetErrorString(e)));
+  DeviceGuard guard(desc->device);
+  {
+    int cur = -1;
+    if ((e = hipGetDevice(&cur)) != hipSuccess || cur != desc->device)
+      return bail(PCLSEG_ERR_HIP, fmt("hipSetDevice(%d): %s", desc->device, hipGetErrorString(e)));
+  }
   const size_t arena_bytes = (size_t)h->g.arena_floats * sizeof(float);
   const size_t mask_bytes = (size_t)h->g.micro_batch * desc->height * desc->width;
   {
@@ -614,9 +826,16 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
     return bail(PCLSEG_ERR_HIP, fmt("event creation: %s", hipGetErrorString(e)));
   h->d_arena = h->d_arena_lane[0];
   h->exact = (desc->flags & PCLSEG_FLAG_EXACT_F32) != 0;
-  if (h->exact) e = hipMalloc((void**)&h->d_w32, (size_t)h->g.packed32_floats * sizeof(float));
-  else e = hipMalloc((void**)&h->d_w16, (size_t)h->g.packed16_halfs * sizeof(_Float16));
+  h->fallback = !h->exact && (desc->flags & PCLSEG_FLAG_RANGE_FALLBACK) != 0;
+  e = hipSuccess;
+  if (h->exact || h->fallback) e = hipMalloc((void**)&h->d_w32, (size_t)h->g.packed32_floats * sizeof(float));
+  if (e == hipSuccess && !h->exact) e = hipMalloc((void**)&h->d_w16, (size_t)h->g.packed16_halfs * sizeof(_Float16));
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, (size_t)h->g.packed_bias_floats * sizeof(float));
+  if (e == hipSuccess && !h->exact) {
+    e = hipMalloc((void**)&h->d_range, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->d_range, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_range, sizeof(unsigned), hipHostMallocDefault);
+  }
   if (e != hipSuccess)
     return bail(e == hipErrorOutOfMemory ? PCLSEG_ERR_OOM : PCLSEG_ERR_HIP,
                 fmt("hipMalloc(parameters): %s", hipGetErrorString(e)));
@@ -626,7 +845,7 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
 
 int pclseg_destroy(pclseg_handle* h) {
   if (!h) return PCLSEG_OK;
-  if (h->d_arena_lane[0] || h->d_bias) (void)hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   for (int l = 0; l < pclseg_handle::kMaxLanes; ++l) {
     if (h->lane_stream[l]) { (void)hipStreamSynchronize(h->lane_stream[l]); (void)hipStreamDestroy(h->lane_stream[l]); }
     if (h->ev_lane[l]) (void)hipEventDestroy(h->ev_lane[l]);
@@ -634,8 +853,17 @@ int pclseg_destroy(pclseg_handle* h) {
     if (h->d_mask_lane[l]) (void)hipFree(h->d_mask_lane[l]);
   }
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-  void* bufs[] = {h->d_w32, h->d_w16, h->d_bias, h->d_stage_in, h->d_stage_mask,
-                  h->d_stage_preds, h->d_stage_probs, h->d_stage_logits};
+  for (int l = 0; l < pclseg_handle::kMaxLanes; ++l) {
+    pclseg_handle::HostLane& L = h->hl[l];
+    void* dev[] = {L.d_in, L.d_maskin, L.d_preds, L.d_probs, L.d_logits};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    if (L.p_in) (void)hipHostFree(L.p_in);
+    if (L.p_mask) (void)hipHostFree(L.p_mask);
+    if (L.ev_bounce) (void)hipEventDestroy(L.ev_bounce);
+  }
+  void* pinned[] = {h->p_preds, h->p_probs, h->p_logits, h->p_mask, h->h_range};
+  for (void* p : pinned) if (p) (void)hipHostFree(p);
+  void* bufs[] = {h->d_w32, h->d_w16, h->d_bias, h->d_range};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   delete h;
@@ -687,8 +915,9 @@ int pclseg_finalize(pclseg_handle* h) {
     auto it = h->g.weight_index.find(name);
     return it == h->g.weight_index.end() ? nullptr : h->host_w[it->second].data();
   };
-  std::vector<float> w32(h->exact ? (size_t)h->g.packed32_floats : 0, 0.0f);
-  std::vector<_Float16> w16(h->exact ? 0 : (size_t)h->g.packed16_halfs, (_Float16)0.0f);
+  const bool want32 = h->exact || h->fallback, want16 = !h->exact;
+  std::vector<float> w32(want32 ? (size_t)h->g.packed32_floats : 0, 0.0f);
+  std::vector<_Float16> w16(want16 ? (size_t)h->g.packed16_halfs : 0, (_Float16)0.0f);
   std::vector<float> bias((size_t)h->g.packed_bias_floats, 0.0f);
   for (const Op& op : h->g.ops) {
     if (op.kind == OP_POOL) continue;
@@ -742,13 +971,13 @@ int pclseg_finalize(pclseg_handle* h) {
       std::vector<double> scale, shift;
       fold_bn(su, f, &scale, &shift);
       pack_bias(su, shift, bias.data() + su.b_off);
-      if (h->exact) pack_w32(op, su, f, scale, w32.data() + su.w32_off);
-      else pack_w16(op, su, f, scale, w16.data() + su.w16_off);
+      if (want32) pack_w32(op, su, f, scale, w32.data() + su.w32_off);
+      if (want16) pack_w16(op, su, f, scale, w16.data() + su.w16_off);
     }
   }
-  HIP_TRY(h, hipSetDevice(h->device));
-  if (h->exact) HIP_TRY(h, hipMemcpy(h->d_w32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
-  else HIP_TRY(h, hipMemcpy(h->d_w16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+  DeviceGuard guard(h->device);
+  if (want32) HIP_TRY(h, hipMemcpy(h->d_w32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (want16) HIP_TRY(h, hipMemcpy(h->d_w16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   h->finalized = true;
   // the Keras-layout copies are no longer needed
@@ -764,8 +993,34 @@ int pclseg_set_stream(pclseg_handle* h, void* hip_stream) {
 
 int pclseg_sync(pclseg_handle* h) {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  bool fired = false;
+  int rc = take_range_flag(h, &fired);
+  if (rc || !fired) return rc;
+  if (!h->fallback || !h->last.valid) return fail(h, PCLSEG_ERR_RANGE, kRangeMsg);
+  // repair: re-run the last asynchronous call with exact float32 products (its buffers are the
+  // caller's and must still be valid, as for any asynchronous call that has not been synchronised)
+  const pclseg_handle::LastCall c = h->last;
+  rc = sweep(h, c.input, c.raw, c.mask_in, c.n, c.preds, c.probs, c.logits, c.mask_out, PCLSEG_MEM_DEVICE, true);
+  if (rc) { drain_after_error(h); return rc; }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return PCLSEG_OK;
+}
+
+void* pclseg_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    g_last_error = fmt("hipHostMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+int pclseg_host_free(void* p) {
+  if (!p) return PCLSEG_OK;
+  HIP_TRY(nullptr, hipHostFree(p));
   return PCLSEG_OK;
 }
 
@@ -796,9 +1051,18 @@ int pclseg_read_tensor(pclseg_handle* h, int index, float* host_out, size_t capa
   const TensorInfo& t = h->g.tensors[index];
   const size_t nfl = (size_t)h->last_count * t.scan_floats();
   if (capacity_floats < nfl) return fail(h, PCLSEG_ERR_BAD_ARG, "host buffer too small");
-  HIP_TRY(h, hipSetDevice(h->device));
+  DeviceGuard guard(h->device);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(host_out, h->d_arena + t.offset, nfl * sizeof(float), hipMemcpyDeviceToHost));
+  if (t.fmt == FMT_S16 && !h->last_exact) {
+    // split-f16 pair format: per pixel C halfs hi then C halfs lo in the same 4*C bytes -> hi + lo
+    const size_t npx = nfl / t.C;
+    std::vector<_Float16> px(2 * (size_t)t.C);
+    for (size_t i = 0; i < npx; ++i) {
+      memcpy(px.data(), host_out + i * t.C, 4 * (size_t)t.C);
+      for (int c = 0; c < t.C; ++c) host_out[i * t.C + c] = (float)px[c] + (float)px[t.C + c];
+    }
+  }
   return PCLSEG_OK;
 }
 

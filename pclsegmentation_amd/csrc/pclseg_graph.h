@@ -36,9 +36,12 @@ struct WeightInfo {
   }
 };
 
+enum TensorFmt { FMT_F32 = 0, FMT_S16 = 1 };  // S16: split-f16 pair format, see pclseg_kernels.h
+
 struct TensorInfo {
   std::string name;
   int H, W, C;
+  int fmt = FMT_F32;
   int def_op = -1, last_op = -1;
   int64_t offset = -1;  // floats, into the activation arena
   int64_t scan_floats() const { return (int64_t)H * W * C; }
@@ -73,10 +76,12 @@ struct Op {
   int nsub = 1;
   SubOp sub[2];
   int ntw = 1, wn = 1;   // kernel template: 16-cout tiles per wave, wave columns per block
-  int mtw = 4;           // kernel template: 16-pixel segments per wave (2 or 4)
+  int mtw = 4;           // kernel template: 16-pixel segments per wave (2, 4 or 8)
+  int nw = 4;            // kernel template: waves per block (4 or 8)
   int ck16 = 64;         // channels per LDS pass, split-f16 mode
   int ck32 = 32;         // channels per LDS pass, exact-f32 mode
   int pool_kh = 1, pool_kw = 1;
+  bool pair = false;     // FIRE expand pair run as merged blocks (conv_kernel PAIR), split-f16 mode
   // optional fused skip branch (SqueezeSegV2 conv1_skip/bn1_skip): BN(conv1x1(sk_in)) is added
   // in the epilogue; `sk` names its Keras tensors, sk.b_off locates [8][C] weights + [C] bias
   int sk_in = -1;
@@ -111,11 +116,11 @@ inline bool op_is_flat(const Op& op) {
   return op.kind == OP_CONV && op.pkh == 1 && op.pkw == 1 && op.sw == 1 && op.ow_mul == 1;
 }
 
-// A block covers 16/wn segments of 16 pixels: 1x1 convs walk the flattened N*H*W pixel row,
-// everything else takes an 8-row tile, 16 or 32 columns wide.
+// A block covers (nw/wn)*mtw segments of 16 pixels: 1x1 convs walk the flattened N*H*W pixel row,
+// everything else takes an 8-row tile, 16, 32 or 64 columns wide.
 inline TileGeom tile_geom(const Op& op) {
   TileGeom t;
-  const int S = (4 / op.wn) * op.mtw;  // segments per block: 4, 8 or 16
+  const int S = (op.nw / op.wn) * op.mtw;  // segments per block: 4, 8, 16 or 32
   if (op_is_flat(op)) { t.TH = 1; t.SEGW = S; }
   else if (S >= 8) { t.TH = 8; t.SEGW = S / 8; }
   else { t.TH = S; t.SEGW = 1; }
@@ -143,6 +148,19 @@ inline int64_t lds_bytes_f32(const Op& op, int ck) {
   return (int64_t)t.PH * t.PW * (std::min(cinp, ck) + 4) * 4;
 }
 
+// Block shape of a merged FIRE expand pair (split-f16 mode).  e = couts of each half.
+//   e >= 128 (the W/8 and W/16 layers, matrix-core / latency bound): 8-wave blocks with large
+//     register tiles — 128 pixels x all or half of the couts per block, patch staged once.
+//   e <= 64  (the high-resolution layers, bandwidth bound): 4-wave blocks, many per CU.
+inline void pair_geometry(Op* op) {
+  static const int big = getenv("PCLSEG_BIGTILE") ? atoi(getenv("PCLSEG_BIGTILE")) : 1;
+  const int nct = (op->sub[1].cout + 15) / 16;
+  if (!big) return;
+  if (nct == 16) { op->nw = 8; op->wn = 8; op->ntw = 2; op->mtw = 8; }        // 128 px x 256 couts
+  else if (nct == 12) { op->nw = 8; op->wn = 4; op->ntw = 3; op->mtw = 4; }   // 128 px x 192 couts
+  else if (nct == 8) { op->nw = 8; op->wn = 4; op->ntw = 2; op->mtw = 4; }    // 128 px x 128 couts
+}
+
 // Kernel configuration + packed-parameter geometry of one op (graph ops and stand-alone ops).
 inline void op_geometry(Op* op) {
   if (op->kind == OP_POOL || op->kind == OP_CAM) return;
@@ -157,12 +175,15 @@ inline void op_geometry(Op* op) {
   // pairs and the 16-cout ops (fire12/13: 47 -> 45 us, 78 -> 70 us), 128-pixel blocks (smaller LDS
   // patch, more co-resident blocks) for the rest (head, 32-cout up-convolutions).
   op->mtw = (op->wn == 1 && op->nsub == 1 && op->ntw != 1) ? 2 : 4;
-  if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw;subname=..."
+  op->nw = 4;
+  if (op->pair) pair_geometry(op);
+  if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw[,nw];subname=..."
     const std::string key = op->sub[0].name + "=";
     const char* hit = strstr(ov, key.c_str());
-    int a = 0, b = 0, c = 0;
-    if (hit && (hit == ov || hit[-1] == ';') && sscanf(hit + key.size(), "%d,%d,%d", &a, &b, &c) == 3) {
-      op->ntw = a; op->wn = b; op->mtw = c;
+    int a = 0, b = 0, c = 0, d = 4;
+    if (hit && (hit == ov || hit[-1] == ';')) {
+      const int got = sscanf(hit + key.size(), "%d,%d,%d,%d", &a, &b, &c, &d);
+      if (got >= 3) { op->ntw = a; op->wn = b; op->mtw = c; op->nw = got == 4 ? d : 4; }
     }
   }
   const int group = op->ntw * op->wn;
@@ -172,12 +193,14 @@ inline void op_geometry(Op* op) {
   }
   const int64_t budget = 64 * 1024;  // default dynamic-LDS limit per block
   // f16 mode: 40 KiB keeps four blocks per CU resident (160 KiB LDS); worth a second channel chunk
-  // from 64 input channels up (head 77 -> 68 us), not for the 48-channel squeezes (35 -> 36 us)
-  const int64_t budget16 = op->cin_t >= 64 ? 40 * 1024 : budget;
+  // from 64 input channels up (head 77 -> 68 us), not for the 48-channel squeezes (35 -> 36 us).
+  // Merged FIRE pairs and 8-wave blocks take the whole patch in one chunk.
+  const int64_t budget16 = (op->cin_t >= 64 && !op->pair && op->nw == 4) ? 40 * 1024 : budget;
   op->ck16 = 64;
   while (op->ck16 > 16 && lds_bytes_f16(*op, op->ck16) > budget16) op->ck16 /= 2;
   op->ck32 = 32;
   while (op->ck32 > 16 && lds_bytes_f32(*op, op->ck32) > budget) op->ck32 /= 2;
+  if (op->pair && op->ck16 < op->cin_t) op->pair = false;   // merged pairs need the patch in one chunk
 }
 
 inline int64_t sub_w32_floats(const Op& op, const SubOp& s) {
@@ -349,30 +372,23 @@ class GraphBuilder {
     return op.out;
   }
 
-  // MaxPool SAME; k x k windows with k > 3 run as two separable passes (1xk then kx1).
+  // MaxPool k x k, strides (1, sw), SAME (the graphs only use 3x3 s2: nets/SqueezeSegV2.py:295,301,305;
+  // CAM's 7x7 s1 pool lives inside cam_kernel).
   int pool(const std::string& name, int in, int k, int sw) {
     const TensorInfo ti = g_->tensors[in];
     int wo, pl;
     same_pad(ti.W, k, sw, &wo, &pl);
-    auto one = [&](const std::string& nm, int src, int kh, int kw, int s, int w_out) {
-      Op op;
-      op.kind = OP_POOL;
-      op.sub[0].name = nm;
-      op.in = src;
-      op.pool_kh = kh;
-      op.pool_kw = kw;
-      op.sw = s;
-      op.cin_t = op.cin_k = ti.C;
-      op.sub[0].cout = ti.C;
-      op.out = tensor(nm, ti.H, w_out, ti.C);
-      push(op);
-      return op.out;
-    };
-    if (k > 3 && sw == 1) {
-      const int rows = one(name + "/rows", in, 1, k, 1, ti.W);
-      return one(name, rows, k, 1, 1, ti.W);
-    }
-    return one(name, in, k, k, sw, wo);
+    Op op;
+    op.kind = OP_POOL;
+    op.sub[0].name = name;
+    op.in = in;
+    op.pool_kh = op.pool_kw = k;
+    op.sw = sw;
+    op.cin_t = op.cin_k = ti.C;
+    op.sub[0].cout = ti.C;
+    op.out = tensor(name, ti.H, wo, ti.C);
+    push(op);
+    return op.out;
   }
 
   void head(const std::string& name, int in, int num_class) {
@@ -416,18 +432,8 @@ inline void build_squeezesegv2(Graph* g) {
   const int x_in = b.tensor("input", H, W, 8);
   g->t_input = x_in;
 
-  auto cam = [&](const std::string& p, int x) {
-    const int C = g->tensors[x].C;
-    if (C == 64 || C == 128) {
-      const int out = b.cam_fused(p, x);
-      b.module_bytes(b.fl(x), b.fl(out));
-      return out;
-    }
-    const int pooled = b.pool(p + "/pool", x, 7, 1);
-    const int sq = b.conv(p + "/squeeze", pooled, 1, 1, C / 16, 1, true, p + "/squeeze_bn", 1);
-    // excitation -> BN -> sigmoid, gate multiplies the un-pooled input (:69-70)
-    const int out = b.tensor(p, g->tensors[x].H, g->tensors[x].W, C);
-    b.conv(p + "/excitation", sq, 1, 1, C, 1, true, p + "/excitation_bn", 3, out, 0, x, true);
+  auto cam = [&](const std::string& p, int x) {   // C is 64 (cam1) or 128 (cam2, cam3): cam_kernel
+    const int out = b.cam_fused(p, x);
     b.module_bytes(b.fl(x), b.fl(out));
     return out;
   };
@@ -589,6 +595,45 @@ inline void plan_workspace(Graph* g) {
   g->arena_floats = top;
 }
 
+// Tensor formats (split-f16 mode only).  A conv output whose ONLY reader is the main input of one
+// other convolution — FIRE squeeze / up-convolution outputs, Darknet's 1x1 bottlenecks — is kept in
+// the split-f16 pair format: the producer splits once, the reader's LDS staging is a plain copy.
+// Everything a residual / skip / pool / CAM / the caller touches stays float32.  A FIRE expand pair
+// whose input is in that format runs as merged blocks (conv_kernel PAIR).
+inline void assign_formats(Graph* g) {
+  if (g->desc.flags & PCLSEG_FLAG_EXACT_F32) return;
+  static const int s16 = getenv("PCLSEG_S16") ? atoi(getenv("PCLSEG_S16")) : 1;   // tuning aid: 0 = all float32
+  static const int pair = getenv("PCLSEG_PAIR") ? atoi(getenv("PCLSEG_PAIR")) : 1;
+  if (!s16) return;
+  const int nt = (int)g->tensors.size();
+  std::vector<int> readers(nt, 0), other(nt, 0), producer(nt, -1), reader_op(nt, -1);
+  for (size_t i = 0; i < g->ops.size(); ++i) {
+    const Op& op = g->ops[i];
+    if (op.in >= 0) {
+      if (op.kind == OP_CONV || op.kind == OP_HEAD) { readers[op.in]++; reader_op[op.in] = (int)i; }
+      else other[op.in]++;
+    }
+    if (op.res1 >= 0) other[op.res1]++;
+    if (op.res2 >= 0) other[op.res2]++;
+    if (op.sk_in >= 0) other[op.sk_in]++;
+    if (op.kind == OP_CONV && op.out >= 0) producer[op.out] = (int)i;
+  }
+  for (int t = 0; t < nt; ++t) {
+    if (t == g->t_input || producer[t] < 0 || readers[t] != 1 || other[t] != 0) continue;
+    const Op& prod = g->ops[producer[t]];
+    const Op& rd = g->ops[reader_op[t]];
+    const bool narrow = prod.nsub == 1 ? (prod.pkh == 1 && prod.pkw == 1) : (prod.ow_mul == 2);  // 1x1 conv or up-conv
+    if (!narrow || g->tensors[t].C % 8 != 0) continue;
+    if (op_is_flat(rd) && rd.nsub == 1) continue;   // LDS-free 1x1 readers split in registers anyway
+    g->tensors[t].fmt = FMT_S16;
+  }
+  if (pair)
+    for (Op& op : g->ops)
+      if (op.kind == OP_CONV && op.nsub == 2 && op.ow_mul == 1 && op.pkh == 3 && op.sub[0].nkh == 1 &&
+          op.sub[0].cout == op.sub[1].cout && g->tensors[op.in].fmt == FMT_S16)
+        op.pair = true;
+}
+
 inline int resolve_micro_batch(const pclseg_desc& d) {
   if (d.micro_batch > 0) return d.micro_batch;
   const int64_t px = (int64_t)d.height * d.width;
@@ -637,6 +682,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
   g->micro_batch = resolve_micro_batch(*d);
   if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) build_squeezesegv2(g);
   else build_darknet(g, d->arch == PCLSEG_ARCH_DARKNET21 ? 21 : 53);
+  assign_formats(g);
   // packed-parameter geometry: exact-f32 fragments, split-f16 fragments, biases
   for (Op& op : g->ops) {
     if (op.kind == OP_POOL) continue;

@@ -74,8 +74,32 @@ struct ConvArgs {
   int nsub;
   int ny;      // blocks per pixel tile (all sub-convs' cout groups)
   int group_major;  // block order, see conv_kernel
+  int in_s16;   // input tensor is in split-f16 pair format (see below), else float32
+  int out_s16;  // write the output in split-f16 pair format
+  unsigned* range_flag;  // sticky: set when a value that is split to f16 hi/lo has |v| >= 65504
+  int skw_lds_off;       // byte offset of the fused skip branch's [9][out_C] weights in dynamic LDS
   ConvSub sub[2];
 };
+
+// Split-f16 pair format ("S16") of an activation tensor [N,H,W,C], C % 8 == 0: per pixel C halfs
+// hi = f16(v) followed by C halfs lo = f16(v - hi) — 4*C bytes per pixel, exactly the float32
+// footprint.  Tensors whose only reader is the LDS staging of one convolution (FIRE squeeze and
+// up-convolution outputs, Darknet's 1x1 bottlenecks) are kept in this form: the producer splits
+// every element once in its epilogue and the consumer's staging becomes a plain 16-byte copy
+// instead of a convert that every cout-group block of a tile would repeat.
+constexpr float kF16Max = 65504.0f;
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+  }
+}
+__device__ __forceinline__ float absmax4(float m, const f32x4 v) {
+  m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
+  return fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
 
 // Blocks are dealt round-robin over the 8 XCDs (private L2 each).  Remap the linear block id so
 // every XCD works on one CONTIGUOUS range of logical ids: neighbouring tiles (shared halo) and the
@@ -84,6 +108,25 @@ struct ConvArgs {
 __device__ __forceinline__ int xcd_remap(int id, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = id & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
+// Activation of a channel quad.  `act` is wave-uniform, so this is three scalar branches around
+// four-wide bodies (a per-element switch with a precise expf/division unrolled over every
+// accumulator register made the epilogue two thirds of the kernel's code).  The sigmoid runs on the
+// transcendental unit (v_exp_f32 + v_rcp_f32, ~1 ulp each).
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+  } else if (act == ACT_LRELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.1f * v[e];
+  } else if (act == ACT_SIGMOID) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v[e]));
+  }
+  return v;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -101,9 +144,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // one wave (needed by the head's argmax) on a 256-pixel block.
 // EPI: which epilogue operands this instantiation carries registers for:
 //   0 none, 1 res1, 2 res1 + res2, 3 fused skip branch (skx), 4 all of them.
-template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI>
-__global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a) {
+// PAIR (split-f16 mode, FIRE expand pair, single channel chunk): the block computes cout group `by`
+// of the 3x3 sub-conv and then the SAME cout group of the 1x1 sub-conv from the one staged patch
+// (the 1x1 is the centre tap), so the pair needs half the blocks and stages half as often.
+// NW = waves per block: 4 (256 threads, four co-resident blocks per CU) or 8 (512 threads, large
+// register tiles, two waves per SIMD that alternate between LDS reads and MFMA bursts): with
+// NW = 8 a block covers (8/WN)*MTW pixel segments x WN*NTW cout tiles per sub-conv, so the deep
+// FIRE layers stage each patch once for 128-256 output channels instead of once per 64.
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int kThreads = NW * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,9 +182,9 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
   const int n = tile / a.tilesH;
   const int h0 = thi * a.TH;
   const int w0 = twi * (a.SEGW * 16);
-  const int si = (a.nsub > 1 && by >= a.sub[0].ny) ? 1 : 0;
+  const int si = PAIR ? 1 : ((a.nsub > 1 && by >= a.sub[0].ny) ? 1 : 0);
   const ConvSub& S = a.sub[si];
-  const int ct0 = (by - (si ? a.sub[0].ny : 0)) * (NTW * WN) + wn * NTW;
+  const int ct0 = (by - ((!PAIR && si) ? a.sub[0].ny : 0)) * (NTW * WN) + wn * NTW;
 
   f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -143,6 +194,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
 
   const float* in_n = a.in + (size_t)n * a.H * a.Win * a.Cin;
   const int npix = a.PH * a.PW;
+  float vmax = 0.f;  // largest |value| this thread split to f16 hi/lo (range guard)
 
   // this wave's segments: (row, column-segment) inside the tile
   int seg_r[MTW], seg_q[MTW];
@@ -152,6 +204,194 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
     seg_r[m] = seg / a.SEGW;
     seg_q[m] = seg - seg_r[m] * a.SEGW;
   }
+
+  // ---------------------------------------------------------------------------- epilogue
+  // The fused skip branch's folded 1x1 weights + bias ([9][out_C] floats) live in LDS behind the
+  // patch: fetched once per block, read in the epilogue on the LDS counter (not behind stores).
+  constexpr bool kSkip = !HEAD && (EPI == 3 || EPI == 4);
+  const float* skw_lds = reinterpret_cast<const float*>(smem_raw + a.skw_lds_off);
+  if constexpr (kSkip) if (a.skx) {
+    f32x4* dst = reinterpret_cast<f32x4*>(smem_raw + a.skw_lds_off);
+    for (int i = tid; i < (9 * a.out_C) >> 2; i += kThreads)
+      dst[i] = *reinterpret_cast<const f32x4*>(a.skw + i * 4);
+  }
+  auto epilogue = [&](const ConvSub& E, f32x4 (&ac)[MTW][NTW]) {
+    // opaque copies of the lane coordinates: everything the epilogue derives from them is computed
+    // HERE, not hoisted above the K loop where it would cost registers for its whole duration
+    int p = lane & 15, g = lane >> 4;
+    asm volatile("" : "+v"(p), "+v"(g));
+    f32x4 bv[NTW];
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn)
+      bv[nn] = *reinterpret_cast<const f32x4*>(E.bias + (ct0 + nn) * 16 + g * 4);
+    if constexpr (!HEAD) {
+      // vmcnt retires loads AND stores in issue order, so a residual load issued after a store
+      // would wait for that store's acknowledgement: tile after tile, the epilogue would pay a full
+      // memory round trip each.  Hence two passes: every residual / skip operand of the whole
+      // accumulator tile is fetched first, then all tiles are finished and stored back to back.
+      constexpr bool kR1 = EPI == 1 || EPI == 2 || EPI == 4;
+      constexpr bool kR2 = EPI == 2 || EPI == 4;
+      constexpr bool kSk = EPI == 3 || EPI == 4;
+      f32x4 r1[kR1 ? MTW : 1][NTW], r2[kR2 ? MTW : 1][NTW], sx0[kSk ? MTW : 1], sx1[kSk ? MTW : 1];
+      size_t pixm[MTW];
+      bool validm[MTW];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int oh = h0 + seg_r[m];
+        const int j = w0 + seg_q[m] * 16 + p;
+        validm[m] = (oh < a.H) && (j < a.Wconv);
+        pixm[m] = ((size_t)n * a.H + oh) * a.Wout + (j * a.ow_mul + E.ow_off);
+      }
+      if constexpr (kR1) if (a.res1) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int nn = 0; nn < NTW; ++nn) {
+            const int co = (ct0 + nn) * 16 + g * 4;
+            const bool ok = validm[m] && co < E.Cout;
+            r1[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res1 + pixm[m] * a.res1_C + E.co_off + co : a.res1);
+          }
+      }
+      if constexpr (kR2) if (a.res2) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int nn = 0; nn < NTW; ++nn) {
+            const int co = (ct0 + nn) * 16 + g * 4;
+            const bool ok = validm[m] && co < E.Cout;
+            r2[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res2 + pixm[m] * a.res2_C + E.co_off + co : a.res2);
+          }
+      }
+      if constexpr (kSk) if (a.skx) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          const float* xp = validm[m] ? a.skx + pixm[m] * 8 : a.skx;
+          sx0[m] = *reinterpret_cast<const f32x4*>(xp);
+          sx1[m] = *reinterpret_cast<const f32x4*>(xp + 4);
+        }
+      }
+#pragma unroll
+      for (int nn = 0; nn < NTW; ++nn) {
+        const int co = (ct0 + nn) * 16 + g * 4;
+        // SqueezeSegV2's conv1_skip + bn1_skip (nets/SqueezeSegV2.py:293,319) evaluated here from
+        // the 8-channel network input instead of round-tripping a 64-channel tensor: this lane's
+        // 8x4 weight block + bias (9 quads, from LDS) is shared by its MTW pixels
+        f32x4 skwv[kSk ? 9 : 1];
+        if constexpr (kSk) if (a.skx && co < E.Cout) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c)
+            skwv[c] = *reinterpret_cast<const f32x4*>(skw_lds + E.co_off + co + c * a.out_C);
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          if (validm[m] && co < E.Cout) {
+            f32x4 v = act4(ac[m][nn] + bv[nn], E.act);
+            if constexpr (kR1) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
+            if constexpr (kR2) if (a.res2) v += r2[m][nn];
+            if constexpr (kSk) if (a.skx) {
+              f32x4 z = skwv[8];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = fmaf(sx0[m][c], skwv[c][e], z[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = fmaf(sx1[m][c], skwv[4 + c][e], z[e]);
+              }
+              v += z;
+            }
+            if (F16X3 && a.out_s16) {
+              f16x4 hi, lo;
+              split4(v, hi, lo);
+              vmax = absmax4(vmax, v);
+              _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + pixm[m] * (size_t)(2 * a.out_C) + E.co_off + co;
+              *reinterpret_cast<f16x4*>(o16) = hi;
+              *reinterpret_cast<f16x4*>(o16 + a.out_C) = lo;
+            } else {
+              *reinterpret_cast<f32x4*>(a.out + pixm[m] * a.out_C + E.co_off + co) = v;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int oh = h0 + seg_r[m];
+        const int j = w0 + seg_q[m] * 16 + p;
+        const bool valid = (oh < a.H) && (j < a.Wconv);
+        const int ow = j * a.ow_mul + E.ow_off;
+        const size_t pix = ((size_t)n * a.H + oh) * a.Wout + ow;
+        // segmentation head (reference: nets/SegmentationNetwork.py:58-69).  The NT tiles hold
+        // all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.
+        // A NaN or +inf logit makes every softmax probability of the pixel NaN, and tf.argmax
+        // over all-NaN probabilities yields index 0: such pixels get class 0, never an
+        // out-of-range id.
+        const int NC = E.Cout;
+        float val[NTW * 4];
+        float best = -INFINITY;
+        int bi = 0;
+        bool bad = false;
+#pragma unroll
+        for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int co = nn * 16 + g * 4 + i;
+            const float v = ac[m][nn][i] + bv[nn][i];
+            val[nn * 4 + i] = v;
+            if (co < NC) {
+              if (a.logits && valid) a.logits[pix * NC + co] = v;
+              bad = bad || !(v < INFINITY);   // NaN or +inf
+              if (v > best) { best = v; bi = co; }
+            }
+          }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+          const float ov = __shfl_xor(best, off);
+          const int oi = __shfl_xor(bi, off);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        {
+          int b = bad ? 1 : 0;
+          b |= __shfl_xor(b, 16);
+          b |= __shfl_xor(b, 32);
+          bad = b != 0;
+        }
+        if (a.probs) {
+          // softmax materialised: exp(x - max) / sum, and the argmax is taken over the
+          // probabilities exactly as the reference does (lowest index wins ties).
+          float sum = 0.f;
+#pragma unroll
+          for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (nn * 16 + g * 4 + i < NC) sum += expf(val[nn * 4 + i] - best);
+          sum += __shfl_xor(sum, 16);
+          sum += __shfl_xor(sum, 32);
+          float pbest = -1.f;
+          int pbi = 0;
+#pragma unroll
+          for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int co = nn * 16 + g * 4 + i;
+              if (co < NC) {
+                const float pr = bad ? NAN : expf(val[nn * 4 + i] - best) / sum;
+                if (valid) a.probs[pix * NC + co] = pr;
+                if (pr > pbest) { pbest = pr; pbi = co; }
+              }
+            }
+#pragma unroll
+          for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(pbest, off);
+            const int oi = __shfl_xor(pbi, off);
+            if (ov > pbest || (ov == pbest && oi < pbi)) { pbest = ov; pbi = oi; }
+          }
+          bi = pbi;
+        }
+        if (bad) bi = 0;
+        if (g == 0 && valid) a.preds[pix] = a.mask[pix] ? bi : a.none_index;
+      }
+    }
+  };
 
   if constexpr (!F16X3) {
     // ------------------------------------------------------------ exact float32 matrix cores
@@ -168,7 +408,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
       // batches of kStageBatch so their latencies overlap
       const int lq = cqn == 8 ? 3 : 2;
       const int sq = tid & (cqn - 1);
-      const int spstep = kConvThreads >> lq;
+      const int spstep = kThreads >> lq;
       const int c = c0 + sq * 4;
       const bool cok = c < a.Cin;
       for (int pb = tid >> lq; pb < npix; pb += kStageBatch * spstep) {
@@ -220,6 +460,7 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
         }
       }
     }
+    epilogue(S, acc);
   } else {
     // ------------------------------------------------------------ split-f16 matrix cores
     // LDS: two planes (hi, lo) of [PH*PW][CSh] halfs.  K runs over (tap, 8-channel group)
@@ -228,32 +469,58 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
     _Float16* sm = reinterpret_cast<_Float16*>(smem_raw);
     const int cin8 = (a.Cin + 7) >> 3;
     const int ck8_full = a.CK >> 3;
-    // staged float4 quads per pixel: next power of two of the widest chunk (zero-filled), so the
-    // staging index math is shifts only
+    // staged 16-byte units per pixel: next power of two of the widest chunk (zero-filled), so the
+    // staging index math is shifts only.  float32 input: a unit is a float4 channel quad that
+    // becomes 4 hi + 4 lo halfs; split-f16 input: a unit is 8 hi or 8 lo halfs, copied as is
+    // (the first half of the unit indices addresses the hi plane, the second the lo plane)
     const int qmax = (cin8 < ck8_full ? cin8 : ck8_full) * 2;
     int lq = 1;
     while ((1 << lq) < qmax) ++lq;
     const int qs = 1 << lq;
     const int CSh = qs * 4 + kPadF16;  // halfs per patch pixel
     const int plane = npix * CSh;      // halfs per plane
-    const int ntaps = S.nkh * S.nkw;
-    const int steps_full = (ntaps * ck8_full + 3) >> 2;
-    const int inv_kw = (65536 + S.nkw - 1) / S.nkw;
     int pixoff[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
-      pixoff[m] = ((seg_r[m] + S.th0) * a.PW + (seg_q[m] * 16 + p) * a.sw + S.tw0) * CSh;
+      pixoff[m] = (seg_r[m] * a.PW + (seg_q[m] * 16 + p) * a.sw) * CSh;
 
-    const int sq = tid & (qs - 1);        // this thread's channel quad (fixed: 256 % qs == 0)
+    const int sq = tid & (qs - 1);        // this thread's unit (fixed: kThreads % qs == 0)
     const int spix0 = tid >> lq;
-    const int spstep = kConvThreads >> lq;
+    const int spstep = kThreads >> lq;
     const int hbase = h0 - a.pt, wbase = w0 * a.sw - a.pl;
 
-    int chunk = 0;
-    for (int c8_0 = 0; c8_0 < cin8; c8_0 += ck8_full, ++chunk) {
-      const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
-      if (chunk) __syncthreads();
-      {
+    // stage the channel chunk [c8_0, c8_0 + ck8) (8-channel groups) of the patch into LDS
+    auto stage = [&](const int c8_0, const int ck8) {
+      if (a.in_s16) {
+        constexpr int kB = kStageBatch;
+        const int hq = qs >> 1;
+        const int pl_sel = sq >= hq ? 1 : 0;
+        const int c8u = sq & (hq - 1);
+        const bool cok = c8u < ck8;
+        const _Float16* in16 = reinterpret_cast<const _Float16*>(in_n);  // [H,W][hi Cin | lo Cin]
+        const int coff = pl_sel * a.Cin + (c8_0 + c8u) * 8;
+        _Float16* dbase = sm + pl_sel * plane + c8u * 8;
+        for (int pb = spix0; pb < npix; pb += kB * spstep) {
+          f16x8 v[kB];
+#pragma unroll
+          for (int k = 0; k < kB; ++k) {
+            const int pix = pb + k * spstep;
+            const int pr = (int)(((unsigned)pix * (unsigned)a.inv_pw) >> 20);
+            const int pc = pix - pr * a.PW;
+            const int h = hbase + pr;
+            const int w = wbase + pc;
+            const bool ok = cok && pix < npix && h >= 0 && h < a.H && w >= 0 && w < a.Win;
+            const _Float16* src = ok ? in16 + ((size_t)h * a.Win + w) * (size_t)(2 * a.Cin) + coff : in16;
+            const f16x8 t = *reinterpret_cast<const f16x8*>(src);
+            v[k] = ok ? t : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          }
+#pragma unroll
+          for (int k = 0; k < kB; ++k) {
+            const int pix = pb + k * spstep;
+            if (pix < npix && cok) *reinterpret_cast<f16x8*>(dbase + pix * CSh) = v[k];
+          }
+        }
+      } else {
         const int c = c8_0 * 8 + sq * 4;
         const bool cok = (c < a.Cin) && (sq < ck8 * 2);
         for (int pb = spix0; pb < npix; pb += kStageBatch * spstep) {
@@ -274,11 +541,8 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
           for (int k = 0; k < kStageBatch; ++k) {
             const int pix = pb + k * spstep;
             f16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              hi[e] = (_Float16)v[k][e];
-              lo[e] = (_Float16)(v[k][e] - (float)hi[e]);
-            }
+            split4(v[k], hi, lo);
+            vmax = absmax4(vmax, v[k]);
             if (pix < npix) {
               _Float16* dst = sm + pix * CSh + sq * 4;
               *reinterpret_cast<f16x4*>(dst) = hi;
@@ -287,221 +551,95 @@ __global__ __launch_bounds__(kConvThreads, 4) void conv_kernel(const ConvArgs a)
           }
         }
       }
-      __syncthreads();
+    };
 
-      const int nk = ntaps * ck8;
-      const int nsteps = (nk + 3) >> 2;
-      const int inv_ck8 = (65536 + ck8 - 1) / ck8;
-      const _Float16* wbase16 = S.w16 + ((size_t)(chunk * steps_full) * S.nctp + ct0) * 1024 + lane * 8;
-      // Weight fragments stream from L2 through a D-deep register ring: the loads of step s+D
-      // are issued as soon as step s has consumed its slot, so ~D steps of MFMA work cover the
-      // L2 latency (one step ahead is far too little: a step is only 12*NTW MFMAs).
-      constexpr int D = 2;
-      const int wstep = S.nctp * 1024;  // halfs per K-step of packed fragments
-      f16x8 wh[D][NTW], wl[D][NTW];
+    auto kloop = [&](const ConvSub& K, const int chunk, const int ck8) {
+        const int ntaps = K.nkh * K.nkw;
+        const int steps_full = (ntaps * ck8_full + 3) >> 2;
+        const int nk = ntaps * ck8;
+        const int nsteps = (nk + 3) >> 2;
+        const int inv_ck8 = (65536 + ck8 - 1) / ck8;
+        const int inv_kw = (65536 + K.nkw - 1) / K.nkw;
+        const int origin = (K.th0 * a.PW + K.tw0) * CSh;
+        const _Float16* wbase16 = K.w16 + ((size_t)(chunk * steps_full) * K.nctp + ct0) * 1024 + lane * 8;
+        const int wstep = K.nctp * 1024;  // halfs per K-step of packed fragments
+        auto load_w = [&](int s, f16x8 (&wh)[NTW], f16x8 (&wl)[NTW]) {
+          const int sc = s < nsteps ? s : nsteps - 1;   // trailing refills are unused
+          const _Float16* wp = wbase16 + (unsigned)__mul24(sc, wstep);
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int sd = d < nsteps ? d : nsteps - 1;
-        const _Float16* wp = wbase16 + (unsigned)__mul24(sd, wstep);
+          for (int nn = 0; nn < NTW; ++nn) {
+            wh[nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+            wl[nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+          }
+        };
+        auto step = [&](int s, const f16x8 (&wh)[NTW], const f16x8 (&wl)[NTW]) {
+          int kidx = 4 * s + g;
+          if (kidx >= nk) kidx = 0;  // padded K: its weights are zero, read any valid data
+          // 24-bit multiplies (full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it)
+          const int tap = __mul24(kidx, inv_ck8) >> 16;
+          const int c8 = kidx - __mul24(tap, ck8);
+          const int ti = __mul24(tap, inv_kw) >> 16;
+          const int koff = origin + __mul24(__mul24(ti, a.PW) + (tap - __mul24(ti, K.nkw)), CSh) + c8 * 8;
+          f16x8 xh[MTW], xl[MTW];
 #pragma unroll
-        for (int nn = 0; nn < NTW; ++nn) {
-          wh[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
-          wl[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
-        }
-      }
-      for (int s0 = 0; s0 < nsteps; s0 += D) {
+          for (int m = 0; m < MTW; ++m) {
+            xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
+            xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
+          }
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const int s = s0 + d;
-          if (s < nsteps) {
-            int kidx = 4 * s + g;
-            if (kidx >= nk) kidx = 0;  // padded K: its weights are zero, read any valid data
-            // 24-bit multiplies (full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it)
-            const int tap = __mul24(kidx, inv_ck8) >> 16;
-            const int c8 = kidx - __mul24(tap, ck8);
-            const int ti = __mul24(tap, inv_kw) >> 16;
-            const int koff = __mul24(__mul24(ti, a.PW) + (tap - __mul24(ti, S.nkw)), CSh) + c8 * 8;
-            f16x8 xh[MTW], xl[MTW];
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-              xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
-              xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
-            }
-#pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-              for (int nn = 0; nn < NTW; ++nn) {
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][nn], xh[m], acc[m][nn], 0, 0, 0);
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][nn], xl[m], acc[m][nn], 0, 0, 0);
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][nn], xh[m], acc[m][nn], 0, 0, 0);
-              }
-            // refill this slot with step s + D (clamped: trailing refills are unused)
-            const int sn = (s + D < nsteps) ? s + D : nsteps - 1;
-            const _Float16* wp = wbase16 + (unsigned)__mul24(sn, wstep);
+          for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int nn = 0; nn < NTW; ++nn) {
-              wh[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
-              wl[d][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nn], xh[m], acc[m][nn], 0, 0, 0);
+              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xl[m], acc[m][nn], 0, 0, 0);
+              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xh[m], acc[m][nn], 0, 0, 0);
             }
+        };
+        // Weight fragments stream from L2 through a 2-deep register ring: the loads of step s+2
+        // are issued as soon as step s has consumed its slot.
+        f16x8 whA[NTW], wlA[NTW], whB[NTW], wlB[NTW];
+        load_w(0, whA, wlA);
+        load_w(1, whB, wlB);
+        for (int s0 = 0; s0 < nsteps; s0 += 2) {
+          step(s0, whA, wlA);
+          load_w(s0 + 2, whA, wlA);
+          if (s0 + 1 < nsteps) {
+            step(s0 + 1, whB, wlB);
+            load_w(s0 + 3, whB, wlB);
           }
         }
-      }
-    }
-  }
-
-  // ---------------------------------------------------------------------------- epilogue
-  f32x4 bv[NTW];
+      };
+    if constexpr (PAIR) {
+      // one chunk by construction (host): the 3x3 half, then the 1x1 half (the centre tap of the
+      // same staged patch) through the same accumulators — ONE instance of the K loop and of the
+      // epilogue, run twice (code size: a kernel that does not fit the instruction cache pays for it
+      // on every launch)
+      stage(0, cin8);
+      __syncthreads();
+#pragma nounroll
+      for (int half = 0; half < 2; ++half) {
+        const ConvSub& K = a.sub[1 - half];
+        if (half) {
 #pragma unroll
-  for (int nn = 0; nn < NTW; ++nn)
-    bv[nn] = *reinterpret_cast<const f32x4*>(S.bias + (ct0 + nn) * 16 + g * 4);
-
-  if constexpr (!HEAD) {
-    // vmcnt retires loads AND stores in issue order, so a residual load issued after a store
-    // would wait for that store's acknowledgement: tile after tile, the epilogue would pay a full
-    // memory round trip each.  Hence two passes: every residual / skip operand of the whole
-    // accumulator tile is fetched first, then all tiles are finished and stored back to back.
-    constexpr bool kR1 = EPI == 1 || EPI == 2 || EPI == 4;
-    constexpr bool kR2 = EPI == 2 || EPI == 4;
-    constexpr bool kSk = EPI == 3 || EPI == 4;
-    f32x4 r1[kR1 ? MTW : 1][NTW], r2[kR2 ? MTW : 1][NTW], sx0[kSk ? MTW : 1], sx1[kSk ? MTW : 1];
-    size_t pixm[MTW];
-    bool validm[MTW];
+          for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      const int oh = h0 + seg_r[m];
-      const int j = w0 + seg_q[m] * 16 + p;
-      validm[m] = (oh < a.H) && (j < a.Wconv);
-      pixm[m] = ((size_t)n * a.H + oh) * a.Wout + (j * a.ow_mul + S.ow_off);
-    }
-    if constexpr (kR1) if (a.res1) {
-#pragma unroll
-      for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int nn = 0; nn < NTW; ++nn) {
-          const int co = (ct0 + nn) * 16 + g * 4;
-          const bool ok = validm[m] && co < S.Cout;
-          r1[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res1 + pixm[m] * a.res1_C + S.co_off + co : a.res1);
+            for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    }
-    if constexpr (kR2) if (a.res2) {
-#pragma unroll
-      for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int nn = 0; nn < NTW; ++nn) {
-          const int co = (ct0 + nn) * 16 + g * 4;
-          const bool ok = validm[m] && co < S.Cout;
-          r2[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res2 + pixm[m] * a.res2_C + S.co_off + co : a.res2);
-        }
-    }
-    if constexpr (kSk) if (a.skx) {
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const float* xp = validm[m] ? a.skx + pixm[m] * 8 : a.skx;
-        sx0[m] = *reinterpret_cast<const f32x4*>(xp);
-        sx1[m] = *reinterpret_cast<const f32x4*>(xp + 4);
+        kloop(K, 0, cin8);
+        epilogue(K, acc);
       }
+    } else {
+      int chunk = 0;
+      for (int c8_0 = 0; c8_0 < cin8; c8_0 += ck8_full, ++chunk) {
+        const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
+        if (chunk) __syncthreads();
+        stage(c8_0, ck8);
+        __syncthreads();
+        kloop(S, chunk, ck8);
+      }
+      epilogue(S, acc);
     }
-#pragma unroll
-    for (int nn = 0; nn < NTW; ++nn) {
-      const int co = (ct0 + nn) * 16 + g * 4;
-      // SqueezeSegV2's conv1_skip + bn1_skip (nets/SqueezeSegV2.py:293,319) evaluated here from
-      // the 8-channel network input instead of round-tripping a 64-channel tensor: this lane's
-      // 8x4 weight block + bias (9 quads) is shared by its MTW pixels
-      f32x4 skwv[kSk ? 9 : 1];
-      if constexpr (kSk) if (a.skx && co < S.Cout) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c)
-          skwv[c] = *reinterpret_cast<const f32x4*>(a.skw + S.co_off + co + c * a.out_C);
-      }
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        if (validm[m] && co < S.Cout) {
-          f32x4 v = acc[m][nn] + bv[nn];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
-          if constexpr (kR1) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
-          if constexpr (kR2) if (a.res2) v += r2[m][nn];
-          if constexpr (kSk) if (a.skx) {
-            f32x4 z = skwv[8];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) z[e] = fmaf(sx0[m][c], skwv[c][e], z[e]);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) z[e] = fmaf(sx1[m][c], skwv[4 + c][e], z[e]);
-            }
-            v += z;
-          }
-          *reinterpret_cast<f32x4*>(a.out + pixm[m] * a.out_C + S.co_off + co) = v;
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      const int oh = h0 + seg_r[m];
-      const int j = w0 + seg_q[m] * 16 + p;
-      const bool valid = (oh < a.H) && (j < a.Wconv);
-      const int ow = j * a.ow_mul + S.ow_off;
-      const size_t pix = ((size_t)n * a.H + oh) * a.Wout + ow;
-      // segmentation head (reference: nets/SegmentationNetwork.py:58-69).  The NT tiles hold
-      // all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.
-      const int NC = S.Cout;
-      float val[NTW * 4];
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int nn = 0; nn < NTW; ++nn)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int co = nn * 16 + g * 4 + i;
-          const float v = acc[m][nn][i] + bv[nn][i];
-          val[nn * 4 + i] = v;
-          if (co < NC) {
-            if (a.logits && valid) a.logits[pix * NC + co] = v;
-            if (v > best) { best = v; bi = co; }
-          }
-        }
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        const float ov = __shfl_xor(best, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      }
-      if (a.probs) {
-        // softmax materialised: exp(x - max) / sum, and the argmax is taken over the
-        // probabilities exactly as the reference does (lowest index wins ties).
-        float s = 0.f;
-#pragma unroll
-        for (int nn = 0; nn < NTW; ++nn)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (nn * 16 + g * 4 + i < NC) s += expf(val[nn * 4 + i] - best);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        float pbest = -1.f;
-        int pbi = 0x7fffffff;
-#pragma unroll
-        for (int nn = 0; nn < NTW; ++nn)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int co = nn * 16 + g * 4 + i;
-            if (co < NC) {
-              const float pr = expf(val[nn * 4 + i] - best) / s;
-              if (valid) a.probs[pix * NC + co] = pr;
-              if (pr > pbest) { pbest = pr; pbi = co; }
-            }
-          }
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-          const float ov = __shfl_xor(pbest, off);
-          const int oi = __shfl_xor(pbi, off);
-          if (ov > pbest || (ov == pbest && oi < pbi)) { pbest = ov; pbi = oi; }
-        }
-        bi = pbi;
-      }
-      if (g == 0 && valid) a.preds[pix] = a.mask[pix] ? bi : a.none_index;
-    }
+    if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
   }
 }
 
@@ -573,12 +711,27 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
     t_lo = wave * per;
     t_hi = t_lo + per < nsteps ? t_lo + per : nsteps;
   }
+  float vmax = 0.f;  // range guard: largest |value| split to f16 hi/lo by this thread
+  // one place for the output store: float32 quad, or split-f16 pair format (see ConvArgs)
+  auto store_out = [&](size_t px, int co, const f32x4 v) {
+    if (a.out_s16) {
+      f16x4 hi, lo;
+      split4(v, hi, lo);
+      vmax = absmax4(vmax, v);
+      _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + px * (size_t)(2 * a.out_C) + S.co_off + co;
+      *reinterpret_cast<f16x4*>(o16) = hi;
+      *reinterpret_cast<f16x4*>(o16 + a.out_C) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(a.out + px * a.out_C + S.co_off + co) = v;
+    }
+  };
   if (t_lo < t_hi) load_step(t_lo);
   for (int t = t_lo; t < t_hi; ++t) {
     // split this step's activations, keep its weights, then refill the raw registers
     f16x8 xh[MTW], xl[MTW], ch[NTW], cl[NTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
+      vmax = absmax4(absmax4(vmax, xa[m]), xb[m]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const _Float16 h0 = (_Float16)xa[m][e];
@@ -625,16 +778,15 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
         const int co = (ct0 + nn) * 16 + g * 4;
         if (pvalid[m] && co < S.Cout) {
           const size_t px = (size_t)(pix0 + m * 16 + p);
-          v += *reinterpret_cast<const f32x4*>(S.bias + co);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
+          v = act4(v + *reinterpret_cast<const f32x4*>(S.bias + co), S.act);
           if constexpr (RES) if (a.res1) {
             const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + px * a.res1_C + S.co_off + co);
             v = a.res1_mul ? v * r : v + r;
           }
-          *reinterpret_cast<f32x4*>(a.out + px * a.out_C + S.co_off + co) = v;
+          store_out(px, co, v);
         }
       }
+    if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
     return;
   }
 
@@ -658,14 +810,13 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
       if (pvalid[m] && co < S.Cout) {
-        f32x4 v = acc[m][nn] + bv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], S.act);
+        f32x4 v = act4(acc[m][nn] + bv, S.act);
         if constexpr (RES) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
-        *reinterpret_cast<f32x4*>(a.out + (size_t)(pix0 + m * 16 + p) * a.out_C + S.co_off + co) = v;
+        store_out((size_t)(pix0 + m * 16 + p), co, v);
       }
     }
   }
+  if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
 
 // ---- MaxPool kh x kw, strides (1, sw), TF SAME (padding never wins)            (K6, K7)

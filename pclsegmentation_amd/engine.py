@@ -16,21 +16,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCLSEG_LIB") or os.path.join(_HERE, "libpclseg.so")   # override: A/B of two builds
 
 OK = 0
-ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5, -6
+ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE, ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_KEEP_ACTIVATIONS = 1
 FLAG_EXACT_F32 = 2
+FLAG_RANGE_FALLBACK = 4
 MATH_F16X3, MATH_F32 = 0, 1
 MATH = {"f16x3": MATH_F16X3, "f32": MATH_F32}
 
 ARCH_IDS = {"squeezesegv2": 0, "darknet21": 1, "darknet53": 2}
 ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
 
-# every symbol include/pclseg.h declares (checked by tests/test_abi.py)
+# every symbol include/pclseg.h declares (checked by tests/test_host.py::test_library_exports_every_declared_symbol)
 EXPORTS = [
   "pclseg_version", "pclseg_last_error", "pclseg_plan", "pclseg_create", "pclseg_destroy",
   "pclseg_num_weights", "pclseg_weight_info", "pclseg_set_weight", "pclseg_finalize",
-  "pclseg_set_stream", "pclseg_sync", "pclseg_forward", "pclseg_forward_raw",
+  "pclseg_set_stream", "pclseg_sync", "pclseg_host_alloc", "pclseg_host_free", "pclseg_forward", "pclseg_forward_raw",
   "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
   "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
   "pclseg_op_confusion_matrix", "pclseg_op_project",
@@ -80,6 +81,8 @@ def load_library():
   lib.pclseg_finalize.argtypes = [vp]
   lib.pclseg_set_stream.argtypes = [vp, vp]
   lib.pclseg_sync.argtypes = [vp]
+  lib.pclseg_host_alloc.argtypes = [ctypes.c_size_t]
+  lib.pclseg_host_free.argtypes = [vp]
   lib.pclseg_forward.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32]
   lib.pclseg_forward_raw.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32]
   lib.pclseg_num_tensors.argtypes = [vp]
@@ -99,8 +102,9 @@ def load_library():
                                     ctypes.c_float, vp, vp, vp, vp]
   for name in EXPORTS:
     fn = getattr(lib, name)
-    if name not in ("pclseg_last_error",):
+    if name not in ("pclseg_last_error", "pclseg_host_alloc"):
       fn.restype = ctypes.c_int
+  lib.pclseg_host_alloc.restype = ctypes.c_void_p
   _lib = lib
   return lib
 
@@ -116,6 +120,8 @@ def _raise(rc, handle=None):
     raise KeyError("pclseg: %s" % msg)
   if rc == ERR_OOM:
     raise MemoryError("pclseg: %s" % msg)
+  if rc == ERR_RANGE:
+    raise FloatingPointError("pclseg: %s" % msg)
   raise RuntimeError("pclseg (status %d): %s" % (rc, msg))
 
 

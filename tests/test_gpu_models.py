@@ -224,3 +224,171 @@ def test_inference_cli_reads_a_savedmodel_directory(cuda, tmp_path):
   pred = np.load(str(out / "pred_scan0.npy"))
   decided = g["margin"][0] > MARGIN
   assert np.array_equal(pred[decided], g["preds"][0][decided])
+
+
+def test_full_size_darknet53_kitti_shape(cuda):
+  """BASELINE configs[2] at its real size (Darknet-53, 64x2048, 20 classes, batch 16): one scan
+  against the float64 oracle, batch-composition invariance and a bit-identical repeat.  This is the
+  size at which the deep 64x128-pixel layers run group-major over a 212 MB weight set and the
+  batch is split into micro-batches across the lanes."""
+  mc, model = P.load_model_config("darknet53", "darknet53kitti", height=64, width=2048)
+  model.init_weights(4321)
+  raw = synthetic_scans(16, 64, 2048, mc.INPUT_MEAN, mc.INPUT_STD, 0.78, seed=1234)
+  preds, logits, mask, _ = run_engine(model, raw)
+  none_index = mc.CLASSES.index("None")
+  assert (preds[~mask] == none_index).all() and preds.min() >= 0 and preds.max() < mc.NUM_CLASS
+  lidar, omask = O.normalize_and_mask(raw[5:6], mc.INPUT_MEAN, mc.INPUT_STD)
+  _, opred, ologits = O.forward("darknet53", model.weights, lidar, omask, none_index, num_layers=53,
+                                dtype=np.float64)
+  srt = np.sort(ologits[0], -1)
+  check_against(preds[5], logits[5], mask[5], ologits[0], opred[0], (srt[..., -1] - srt[..., -2]), none_index)
+  for i in (5, 15):
+    p1, l1, _, _ = run_engine(model, raw[i:i + 1])
+    assert np.array_equal(p1[0], preds[i]) and np.array_equal(l1[0], logits[i])
+  p2, l2, _, _ = run_engine(model, raw)
+  assert np.array_equal(p2, preds) and np.array_equal(l2, logits)
+
+
+@pytest.mark.parametrize("stride", [8, 32])
+def test_darknet_output_strides(cuda, stride):
+  """OUTPUT_STRIDE 8 and 32 (nets/Darknet.py:158-181,215-231: which encoder layers shrink W and
+  which decoder layers grow it) against the oracle on every intermediate tensor."""
+  mc, model = P.load_model_config("darknet21", "darknet21", height=16, width=128)
+  mc.OUTPUT_STRIDE = stride
+  model.init_weights(4321)
+  raw = synthetic_scans(2, 16, 128, mc.INPUT_MEAN, mc.INPUT_STD, 0.7, seed=21)
+  preds, logits, mask, eng = run_engine(model, raw, flags=E.FLAG_KEEP_ACTIVATIONS)
+  lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  taps = {}
+  _, opred, ologits = O.forward("darknet21", model.weights, lidar, omask, mc.CLASSES.index("None"),
+                                num_layers=21, output_stride=stride, dtype=np.float64, taps=taps)
+  names = [t[0] for t in eng.tensors()]
+  checked = 0
+  for tap, want in taps.items():
+    if tap == "logits" or tap not in names:
+      continue
+    got = eng.read_tensor(names.index(tap))
+    assert got.shape == want.shape, (tap, got.shape, want.shape)
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), tap
+    checked += 1
+  assert checked > 20
+  assert np.abs(logits - ologits).max() <= LOGIT_TOL
+
+
+def test_nan_pixel_never_yields_an_out_of_range_class(cuda):
+  """A scan pixel with depth > 0 but NaN coordinates (a corrupt file) makes the logits of every pixel
+  in its receptive field NaN.  The reference's softmax then yields NaN probabilities and tf.argmax
+  over them index 0; the predictions must stay inside [0, NC) (here: 0 where valid) and every other
+  pixel must keep its regular result."""
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  raw = synthetic_scans(2, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=8)
+  clean_preds, clean_logits, _, _ = run_engine(model, raw)
+  bad = raw.copy()
+  bad[1, 10, 100, :3] = np.nan
+  bad[1, 10, 100, 4] = 7.0
+  for flags in (0, E.FLAG_EXACT_F32):
+    model._drop_engines()
+    preds, logits, mask, _ = run_engine(model, bad, flags=flags)
+    assert preds.min() >= 0 and preds.max() < mc.NUM_CLASS
+    nan_px = np.isnan(logits).any(-1)
+    assert nan_px[1].any() and not nan_px[0].any()
+    assert (preds[nan_px & mask] == 0).all() and (preds[~mask] == mc.CLASSES.index("None")).all()
+    if flags == 0:
+      assert np.array_equal(preds[0], clean_preds[0]) and np.array_equal(logits[0], clean_logits[0])
+    probs, p2 = model([*O.normalize_and_mask(bad, mc.INPUT_MEAN, mc.INPUT_STD)])
+    assert np.isnan(probs.numpy()[nan_px]).all() and np.array_equal(p2.numpy(), preds)
+  model._drop_engines()
+
+
+def test_split_f16_range_guard_and_exact_fallback(cuda):
+  """Default arithmetic carries operands as f16 hi/lo pairs and needs |activation| < 65504.  With
+  conv1's kernel scaled so that activations leave that range the default engine must SAY so
+  (PCLSEG_ERR_RANGE -> FloatingPointError) instead of returning NaN-derived classes; exact-f32 mode
+  still matches the oracle, and PCLSEG_FLAG_RANGE_FALLBACK repairs the call transparently."""
+  import torch
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  w = dict(model.weights)
+  w["conv1/kernel"] = w["conv1/kernel"] * np.float32(3.0e4)
+  model.set_weights(w)
+  raw = synthetic_scans(2, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=13)
+  lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  taps = {}
+  _, opred, ologits = O.forward("squeezesegv2", model.weights, lidar, omask, 10, dtype=np.float64, taps=taps)
+  assert np.abs(taps["conv1"]).max() > 65504          # the premise: out of the f16 range
+  scale = np.abs(ologits).max()
+  srt = np.sort(ologits, -1)
+  decided = (srt[..., -1] - srt[..., -2]) > 1e-4 * scale
+  with pytest.raises(FloatingPointError):
+    run_engine(model, raw)
+  model._drop_engines()
+  p_exact, l_exact, _, _ = run_engine(model, raw, flags=E.FLAG_EXACT_F32)
+  assert np.abs(l_exact - ologits).max() <= 2e-5 * scale
+  assert np.array_equal(p_exact[decided], opred[decided])
+  model._drop_engines()
+  p_fb, l_fb, _, _ = run_engine(model, raw, flags=E.FLAG_RANGE_FALLBACK)
+  assert np.array_equal(p_fb, p_exact) and np.array_equal(l_fb, l_exact)
+  # asynchronous (device-memory) calls: the guard is reported / repaired by sync()
+  for flags, expect_error in ((0, True), (E.FLAG_RANGE_FALLBACK, False)):
+    model._drop_engines()
+    eng = model.engine(32, 240, flags)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_preds = torch.empty((2, 32, 240), dtype=torch.int32, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.forward_raw(d_raw, 2, d_preds, None, None, None, mem=E.MEM_DEVICE)
+    if expect_error:
+      with pytest.raises(FloatingPointError):
+        eng.sync()
+      eng.sync()                                        # the flag is sticky until reported, then cleared
+    else:
+      eng.sync()
+      assert np.array_equal(d_preds.cpu().numpy(), p_exact)
+  model._drop_engines()
+
+
+def test_host_boundary_pinned_and_pageable_agree_with_device(cuda):
+  """PCLSEG_MEM_HOST with page-locked buffers (direct DMA per micro-batch on the lane streams), with
+  pageable buffers (pinned bounce slabs) and PCLSEG_MEM_DEVICE give bit-identical outputs, for a batch
+  that spans several micro-batches per lane and has a ragged tail."""
+  import torch
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  n, h, w = 11, 32, 240
+  raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=17)
+  model.micro_batch = 2
+  eng = model.engine(h, w)
+  d_raw = torch.from_numpy(raw).cuda()
+  d_preds = torch.empty((n, h, w), dtype=torch.int32, device="cuda")
+  d_logits = torch.empty((n, h, w, mc.NUM_CLASS), dtype=torch.float32, device="cuda")
+  eng.set_stream(torch.cuda.current_stream().cuda_stream)
+  eng.forward_raw(d_raw, n, d_preds, None, d_logits, None, mem=E.MEM_DEVICE)
+  eng.sync()
+  want_p, want_l = d_preds.cpu().numpy(), d_logits.cpu().numpy()
+  lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  for pinned in (True, False):
+    mk = (lambda *s, dtype: torch.empty(s, dtype=dtype).pin_memory()) if pinned else \
+         (lambda *s, dtype: torch.empty(s, dtype=dtype))
+    h_raw = mk(n, h, w, 5, dtype=torch.float32)
+    h_raw.copy_(torch.from_numpy(raw))
+    h_preds, h_logits = mk(n, h, w, dtype=torch.int32), mk(n, h, w, mc.NUM_CLASS, dtype=torch.float32)
+    h_probs, h_mask = mk(n, h, w, mc.NUM_CLASS, dtype=torch.float32), mk(n, h, w, dtype=torch.uint8)
+    for _ in range(2):    # second call reuses the staging slabs
+      h_preds.zero_()
+      eng.forward_raw(h_raw, n, h_preds, h_probs, h_logits, h_mask, mem=E.MEM_HOST)
+      assert np.array_equal(h_logits.numpy(), want_l)
+      assert np.array_equal(h_mask.numpy().astype(bool), omask)
+      assert np.allclose(h_probs.numpy().sum(-1), 1.0, atol=1e-5)
+      # with probabilities materialised the argmax runs over them (same classes off exact ties)
+      srt = np.sort(want_l, -1)
+      decided = (srt[..., -1] - srt[..., -2]) > 1e-6
+      assert np.array_equal(h_preds.numpy()[decided], want_p[decided])
+    # the reference-shaped entry (normalised lidar + mask) through the same boundary
+    h_lidar = mk(n, h, w, 6, dtype=torch.float32)
+    h_lidar.copy_(torch.from_numpy(lidar.astype(np.float32)))
+    h_m = mk(n, h, w, dtype=torch.uint8)
+    h_m.copy_(torch.from_numpy(omask.astype(np.uint8)))
+    eng.forward(h_lidar, h_m, n, h_preds, None, h_logits, mem=E.MEM_HOST)
+    assert np.array_equal(h_preds.numpy(), want_p) and np.array_equal(h_logits.numpy(), want_l)
+  model.micro_batch = 0
+  model._drop_engines()
