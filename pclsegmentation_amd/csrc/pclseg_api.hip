@@ -369,7 +369,11 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
-  if (pair) return launch_conv_pair(op, epi, grid, lds, s, a);
+  if (pair) {
+    static const int wt = getenv("PCLSEG_WT") ? atoi(getenv("PCLSEG_WT")) : 1;
+    a.wt = (wt && !a.res1 && op.nw == 4) ? 1 : 0;   // pays for the 4-wave pairs that only write (see store_quad)
+    return launch_conv_pair(op, epi, grid, lds, s, a);
+  }
   if (op.kind == OP_HEAD)
     return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
                  : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);

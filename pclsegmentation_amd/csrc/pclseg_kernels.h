@@ -77,6 +77,7 @@ struct ConvArgs {
   int in_s16;   // input tensor is in split-f16 pair format (see below), else float32
   int out_s16;  // write the output in split-f16 pair format
   unsigned* range_flag;  // sticky: set when a value that is split to f16 hi/lo has |v| >= 65504
+  int wt;                // write-through output stores (see store_quad)
   int skw_lds_off;       // byte offset of the fused skip branch's [9][out_C] weights in dynamic LDS
   ConvSub sub[2];
 };
@@ -96,6 +97,15 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
     lo[e] = (_Float16)(v[e] - (float)hi[e]);
   }
 }
+// Output stores.  A plain store leaves the line dirty in the XCD's L2 until the end-of-kernel
+// write-back; `sc1` writes through.  Measured per layer: write-through takes
+// 2-3.5 us (10-12 %) off the FIRE expand pairs that only write (fire2-fire7), and ADDS 6-8 us to the
+// ones that also read a skip tensor (fire10-fire13) — hence a per-launch switch (ConvArgs::wt).
+__device__ __forceinline__ void store_quad(float* dst, const f32x4 v, const bool write_through) {
+  if (write_through) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+  else *reinterpret_cast<f32x4*>(dst) = v;
+}
+
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
   return fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
               *reinterpret_cast<f16x4*>(o16) = hi;
               *reinterpret_cast<f16x4*>(o16 + a.out_C) = lo;
             } else {
-              *reinterpret_cast<f32x4*>(a.out + pixm[m] * a.out_C + E.co_off + co) = v;
+              store_quad(a.out + pixm[m] * a.out_C + E.co_off + co, v, a.wt != 0);
             }
           }
         }
