@@ -328,8 +328,9 @@ def main():
     elapsed, dev_ms = time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence)
     eng.sync()   # also reports a split-f16 range overflow (PCLSEG_ERR_RANGE) instead of timing garbage
     if world > 1:
-      t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
-      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+      red_dev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+      t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=red_dev)
+      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # MAX over ranks
       elapsed, dev_ms = float(t[0]), float(t[1])
     res = {"mc": mc, "model": model, "eng": eng, "weights": weights, "info": info, "batch": batch,
            "scans": scans, "preds": preds, "elapsed": elapsed, "dev_ms": dev_ms, "h": h, "w": w,

@@ -236,6 +236,39 @@ int pclseg_op_project(const float* points, size_t m, int h, int w, float fov_up,
                       float empty, float* image5, int32_t* proj_idx, uint64_t* scratch,
                       void* hip_stream);
 
+/* The other projection variants of the reference's converters, same scatter / gather pair:
+ *   row_mode  PCLSEG_PROJ_ROW_FOV  row from the elevation angle (fov_up / fov_down, degrees)
+ *             PCLSEG_PROJ_ROW_RING row = H-1-ring_index, laserscan_nuscenes.py:191-223
+ *                                  (do_range_projection_ring), convert_validation_pcd_to_npy.py:147-153
+ *   col_mode  PCLSEG_PROJ_COL_FULL  360 degree azimuth, laserscan_*.py
+ *             PCLSEG_PROJ_COL_FRONT column = (int)((left_phi - atan2(y,x)) / ((right_phi+left_phi)/W)),
+ *                                  points outside the window dropped (convert_validation_pcd_to_npy.py:
+ *                                  120-137; radians)
+ *   winner    PCLSEG_PROJ_NEAREST  nearest point of a pixel wins (the reference's depth-sorted scatter)
+ *             PCLSEG_PROJ_LAST     last point in input order wins (plain fancy-index assignment)
+ *   out_channels 5: x,y,z,remission,depth; 6: + label (SemLaserScan.do_label_projection and the
+ *             converters' learning_map, dataset_convert/semantic_kitti.py:150-179, nu_dataset.py:157-167;
+ *             empty pixels carry label_lut[0], or 0 without a table); 7: + mask = depth > 0.
+ *   points    float32 [m, point_stride], x,y,z at 0..2, remission at 3; ring int32 [m] (ring rows);
+ *   depth     optional float32 [m] (NULL: float32 norm of xyz); labels optional int32 [m];
+ *   label_lut optional int32 [lut_size]: label -> train id (out of range -> -1).
+ *   image float32 [H,W,out_channels], proj_idx int32 [H,W] (optional), scratch uint64 [H*W]: device. */
+enum { PCLSEG_PROJ_ROW_FOV = 0, PCLSEG_PROJ_ROW_RING = 1 };
+enum { PCLSEG_PROJ_COL_FULL = 0, PCLSEG_PROJ_COL_FRONT = 1 };
+enum { PCLSEG_PROJ_NEAREST = 0, PCLSEG_PROJ_LAST = 1 };
+typedef struct pclseg_proj_desc {
+  int32_t h, w;
+  int32_t row_mode, col_mode, winner;
+  int32_t out_channels;
+  float fov_up, fov_down; /* degrees, PCLSEG_PROJ_ROW_FOV */
+  float empty;            /* value of x,y,z,remission,depth where no point landed */
+  double left_phi, right_phi; /* radians, PCLSEG_PROJ_COL_FRONT */
+} pclseg_proj_desc;
+int pclseg_op_project_ex(const pclseg_proj_desc* desc, const float* points, int point_stride, size_t m,
+                         const int32_t* ring, const float* depth, const int32_t* labels,
+                         const int32_t* label_lut, int lut_size, float* image, int32_t* proj_idx,
+                         uint64_t* scratch, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

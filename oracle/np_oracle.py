@@ -387,3 +387,60 @@ def range_projection(points, H, W, fov_up, fov_down):
   proj_rem[py, px] = rem[order]
   proj_idx[py, px] = np.arange(depth.shape[0])[order]
   return proj_range, proj_xyz, proj_rem, proj_idx
+
+
+def range_projection_ring(points, ring_index, H, W):
+  """Ring-index projection, restating dataset_convert/laserscan_nuscenes.py:191-223
+  (LaserScan.do_range_projection_ring): column from the azimuth exactly as above, row =
+  H-1-ring_index, NO depth ordering — plain fancy-index assignment in input order, so the LAST
+  point of a pixel wins.  Pinned by tests/golden/projection2_ring_*.npz (outputs of the
+  reference's own code).  Returns (proj_range, proj_xyz, proj_remission, proj_idx, proj_mask)."""
+  points = np.asarray(points, np.float32)
+  xyz, rem = points[:, :3], points[:, 3]
+  depth = np.linalg.norm(xyz, 2, axis=1)
+  yaw = -np.arctan2(xyz[:, 1], xyz[:, 0])
+  proj_x = 0.5 * (yaw / np.pi + 1.0)
+  proj_x *= W
+  proj_x = np.maximum(0, np.minimum(W - 1, np.floor(proj_x))).astype(np.int32)
+  proj_y = (H - 1) - np.asarray(ring_index, np.int32)
+  proj_range = np.full((H, W), -1, np.float32)
+  proj_xyz = np.full((H, W, 3), -1, np.float32)
+  proj_rem = np.full((H, W), -1, np.float32)
+  proj_idx = np.full((H, W), -1, np.int32)
+  proj_range[proj_y, proj_x] = depth
+  proj_xyz[proj_y, proj_x] = xyz
+  proj_rem[proj_y, proj_x] = rem
+  proj_idx[proj_y, proj_x] = np.arange(depth.shape[0])
+  return proj_range, proj_xyz, proj_rem, proj_idx, (proj_idx > 0).astype(np.float32)
+
+
+def label_projection(proj_idx, labels, learning_map=None):
+  """SemLaserScan.do_label_projection (laserscan_nuscenes.py:377-383): labels gathered through
+  proj_idx, pixels without a point keep 0; then, optionally, the converters' learning_map
+  (dataset_convert/semantic_kitti.py:145,165: np.vectorize(dict.get) over the label image)."""
+  out = np.zeros(proj_idx.shape, np.int32)
+  mask = proj_idx >= 0
+  out[mask] = np.asarray(labels)[proj_idx[mask]]
+  if learning_map is not None:
+    out = np.vectorize(learning_map.get)(out)
+  return out
+
+
+def information_map(pcl, H=32, W=240, left_phi=np.radians(24.32), right_phi=np.radians(22.23)):
+  """Front-view map of preprocessing/convert_validation_pcd_to_npy.py:97-156: pcl [M,7] = x,y,z,i,
+  ring,depth,label -> [H,W,7] float64 = x,y,z,i,d,label,mask; column = int((left_phi - atan2(y,x)) /
+  ((right_phi+left_phi)/W)) (truncation toward zero), out-of-window points removed, row = H-1-ring,
+  last point wins."""
+  pcl = np.asarray(pcl, np.float64)
+  x, y, z, i = pcl[:, 0], pcl[:, 1], pcl[:, 2], pcl[:, 3]
+  r, d, l = pcl[:, 4].astype(int), pcl[:, 5], pcl[:, 6].astype(int)
+  dphi = (right_phi + left_phi) / W
+  col = ((left_phi - np.arctan2(y, x)) / dphi).astype(int)
+  mask = np.zeros_like(l)
+  mask[d > 0] = 1
+  keep = ~np.logical_or(col < 0, col >= W)
+  out = np.zeros((H, W, 7))
+  rows = (H - 1) - r[keep]
+  for c, v in enumerate((x, y, z, i, d, l, mask)):
+    out[rows, col[keep], c] = v[keep]
+  return out

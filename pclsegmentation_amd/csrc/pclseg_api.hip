@@ -1148,7 +1148,7 @@ int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int st
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_max_pool");
   if (c % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "C must be a multiple of 4");
   if (k > 3 && stride_w == 1) {
-    // separable, exactly as the graph runs CAM's 7x7 pool: rows (1xk) then columns (kx1)
+    // separable: rows (1xk) then columns (kx1) — bit-identical to the k x k window (max is associative)
     DevBuf tmp;
     HIP_TRY(nullptr, hipMalloc(&tmp.p, (size_t)n * h * w * c * sizeof(float)));
     HIP_TRY(nullptr, launch_pool(x, (float*)tmp.p, n, h, w, c, 1, k, 1, nullptr));
@@ -1196,26 +1196,60 @@ int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size
   return PCLSEG_OK;
 }
 
+int pclseg_op_project_ex(const pclseg_proj_desc* d, const float* points, int point_stride, size_t m,
+                         const int32_t* ring, const float* depth, const int32_t* labels,
+                         const int32_t* label_lut, int lut_size, float* image, int32_t* proj_idx,
+                         uint64_t* scratch, void* hip_stream) {
+  if (!d || !points || !image || !scratch || d->h <= 0 || d->w <= 0 || m > 0x7ffffffeull || point_stride < 4)
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_project_ex");
+  if (d->row_mode < 0 || d->row_mode > 1 || d->col_mode < 0 || d->col_mode > 1 || d->winner < 0 || d->winner > 1 ||
+      d->out_channels < 5 || d->out_channels > 7)
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "op_project_ex: unknown mode or out_channels not in [5,7]");
+  if (d->row_mode == PCLSEG_PROJ_ROW_RING && !ring)
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "op_project_ex: ring rows need the ring index array");
+  if (label_lut && lut_size <= 0) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "op_project_ex: empty label table");
+  ProjArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.H = d->h; pa.W = d->w;
+  pa.row_mode = d->row_mode; pa.col_mode = d->col_mode; pa.winner = d->winner; pa.out_c = d->out_channels;
+  if (d->row_mode == PCLSEG_PROJ_ROW_FOV) {
+    const double up = (double)d->fov_up / 180.0 * M_PI, down = (double)d->fov_down / 180.0 * M_PI;
+    const double fov = std::fabs(down) + std::fabs(up);
+    if (!(fov > 0.0)) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "field of view must be positive");
+    pa.fdown = (float)std::fabs(down); pa.ffov = (float)fov;
+  }
+  pa.fpi = (float)M_PI;
+  if (d->col_mode == PCLSEG_PROJ_COL_FRONT) {
+    pa.left_phi = d->left_phi;
+    pa.dphi = (d->right_phi + d->left_phi) / (double)d->w;
+    if (!(pa.dphi > 0.0)) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "front window must have a positive width");
+  }
+  pa.stride = point_stride;
+  pa.ring = ring; pa.depth = depth; pa.labels = labels; pa.lut = label_lut; pa.lut_size = lut_size;
+  pa.empty = d->empty;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int npix = d->h * d->w;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(scratch);
+  hipLaunchKernelGGL(proj_init_kernel, dim3(stream_blocks((size_t)npix)), dim3(256), 0, s, keys, npix,
+                     d->winner == PCLSEG_PROJ_NEAREST ? ~0ull : 0ull);
+  if (m) hipLaunchKernelGGL(proj_scatter_kernel, dim3(stream_blocks(m)), dim3(256), 0, s, points, m, keys, pa);
+  hipLaunchKernelGGL(proj_gather_kernel, dim3(stream_blocks((size_t)npix)), dim3(256), 0, s, points, keys,
+                     npix, image, proj_idx, pa);
+  HIP_TRY(nullptr, hipGetLastError());
+  return PCLSEG_OK;
+}
+
 int pclseg_op_project(const float* points, size_t m, int h, int w, float fov_up, float fov_down,
                       float empty, float* image5, int32_t* proj_idx, uint64_t* scratch,
                       void* hip_stream) {
-  if (!points || !image5 || !scratch || h <= 0 || w <= 0 || m > 0x7fffffffull)
-    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_project");
-  const double up = (double)fov_up / 180.0 * M_PI, down = (double)fov_down / 180.0 * M_PI;
-  const double fov = std::fabs(down) + std::fabs(up);
-  if (!(fov > 0.0)) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "field of view must be positive");
-  ProjArgs pa;
-  pa.H = h; pa.W = w;
-  pa.fpi = (float)M_PI; pa.fdown = (float)std::fabs(down); pa.ffov = (float)fov;
-  hipStream_t s = (hipStream_t)hip_stream;
-  const int npix = h * w;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(scratch);
-  hipLaunchKernelGGL(proj_init_kernel, dim3(stream_blocks((size_t)npix)), dim3(256), 0, s, keys, npix);
-  if (m) hipLaunchKernelGGL(proj_scatter_kernel, dim3(stream_blocks(m)), dim3(256), 0, s, points, m, keys, pa);
-  hipLaunchKernelGGL(proj_gather_kernel, dim3(stream_blocks((size_t)npix)), dim3(256), 0, s, points, keys,
-                     npix, empty, image5, proj_idx);
-  HIP_TRY(nullptr, hipGetLastError());
-  return PCLSEG_OK;
+  pclseg_proj_desc d;
+  memset(&d, 0, sizeof(d));
+  d.h = h; d.w = w;
+  d.row_mode = PCLSEG_PROJ_ROW_FOV; d.col_mode = PCLSEG_PROJ_COL_FULL; d.winner = PCLSEG_PROJ_NEAREST;
+  d.out_channels = 5;
+  d.fov_up = fov_up; d.fov_down = fov_down; d.empty = empty;
+  return pclseg_op_project_ex(&d, points, 4, m, nullptr, nullptr, nullptr, nullptr, 0, image5, proj_idx,
+                              scratch, hip_stream);
 }
 
 }  // extern "C"

@@ -1188,64 +1188,114 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restric
   }
 }
 
-// ---- spherical projection: point cloud -> range image (the step before the network;
-// reference: dataset_convert/laserscan_semantic_kitti.py:106-166, LaserScan.do_range_projection).
-// The reference sorts the points by decreasing depth and scatters them, so the NEAREST point
-// wins a pixel.  Here: one 64-bit atomicMin per point on key = (depth bits << 32) | point index
-// (positive floats order like their bit patterns; equal depths -> lowest index), then one gather
-// per pixel.  The float32 arithmetic follows NumPy's operation order with contraction disabled;
-// atan2 / asin are evaluated in float64 and rounded once.  Points at the origin are skipped.
+// ---- spherical projection: point cloud -> range image (the step before the network).
+// Three reference variants share one scatter / gather pair:
+//   rows   FOV : py = floor((1 - (asin(z/depth) + |fov_down|) / fov) * H), clamped
+//                (dataset_convert/laserscan_semantic_kitti.py:106-166, laserscan_nuscenes.py:226-288)
+//          RING: py = H - 1 - ring_index          (laserscan_nuscenes.py:191-223,
+//                preprocessing/convert_validation_pcd_to_npy.py:147-153)
+//   cols   FULL : px = floor(0.5 * (-atan2(y,x)/pi + 1) * W), clamped (float32 arithmetic in NumPy's
+//                 operation order, contraction disabled; atan2/asin in float64, rounded once)
+//          FRONT: px = (int)((left_phi - atan2(y,x)) / ((right_phi+left_phi)/W)) in float64,
+//                 truncated toward zero; points outside [0, W) are dropped
+//                 (convert_validation_pcd_to_npy.py:120-137)
+//   winner NEAREST: the reference sorts by decreasing depth and scatters, so the nearest point wins:
+//                 one 64-bit atomicMin on (depth bits << 32) | index (positive floats order like their
+//                 bit patterns; equal depths -> lowest index)
+//          LAST : plain fancy-index assignment in input order, the LAST point of a pixel wins:
+//                 atomicMax on index + 1 (0 = empty)
+// then one gather per pixel: x, y, z, remission, depth [, label through an optional look-up table
+// (the converters' learning_map) [, mask = depth > 0]].  Points at the origin are skipped in FOV mode.
 struct ProjArgs {
   int H, W;
+  int row_mode, col_mode, winner, out_c;
   float fpi, fdown, ffov;  // float32(pi), float32(|fov_down| rad), float32(fov rad)
+  double left_phi, dphi;   // FRONT columns
+  int stride;              // floats per point (x, y, z at 0..2, remission at 3)
+  const int32_t* ring;     // RING rows
+  const float* depth;      // optional per-point depth (else the float32 norm)
+  const int32_t* labels;   // optional
+  const int32_t* lut;      // optional label look-up table
+  int lut_size;
+  float empty;
 };
 
-__global__ __launch_bounds__(256) void proj_init_kernel(unsigned long long* __restrict__ keys, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] = ~0ull;
+__global__ __launch_bounds__(256) void proj_init_kernel(unsigned long long* __restrict__ keys, int n,
+                                                        unsigned long long v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) keys[i] = v;
 }
 
 __global__ __launch_bounds__(256) void proj_scatter_kernel(const float* __restrict__ pts, size_t m,
                                                            unsigned long long* __restrict__ keys,
                                                            const ProjArgs a) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
-    const f32x4 pt = *reinterpret_cast<const f32x4*>(pts + i * 4);
+    const float* pt = pts + i * a.stride;
     const float x = pt[0], y = pt[1], z = pt[2];
-    float depth, px, py;
+    float depth;
+    int ix, iy;
     {
 #pragma clang fp contract(off)   // NumPy does not fuse multiply-add: keep every rounding
       const float d2 = (x * x + y * y) + z * z;
-      depth = sqrtf(d2);
-      if (!(depth > 0.0f)) continue;
-      const float yaw = -(float)atan2((double)y, (double)x);
-      const float pitch = (float)asin((double)(z / depth));
-      px = 0.5f * (yaw / a.fpi + 1.0f);
-      py = 1.0f - (pitch + a.fdown) / a.ffov;
-      px = floorf(px * (float)a.W);
-      py = floorf(py * (float)a.H);
+      depth = a.depth ? a.depth[i] : sqrtf(d2);
+      if (a.col_mode == 0) {
+        const float yaw = -(float)atan2((double)y, (double)x);
+        float px = 0.5f * (yaw / a.fpi + 1.0f);
+        px = floorf(px * (float)a.W);
+        ix = (int)fmaxf(0.0f, fminf((float)(a.W - 1), px));
+      } else {
+        const double phi = atan2((double)y, (double)x);
+        const double c = (a.left_phi - phi) / a.dphi;
+        if (!(c > -2147483648.0 && c < 2147483648.0)) continue;
+        ix = (int)c;                                   // astype(int): truncation toward zero
+        if (ix < 0 || ix >= a.W) continue;             // np.delete of the out-of-window points
+      }
+      if (a.row_mode == 0) {
+        if (!(depth > 0.0f)) continue;
+        const float pitch = (float)asin((double)(z / depth));
+        float py = 1.0f - (pitch + a.fdown) / a.ffov;
+        py = floorf(py * (float)a.H);
+        iy = (int)fmaxf(0.0f, fminf((float)(a.H - 1), py));
+      } else {
+        iy = a.H - 1 - a.ring[i];
+        if (iy < 0) iy += a.H;                         // NumPy negative index wraps once
+        if (iy < 0 || iy >= a.H) continue;             // (the reference would raise IndexError)
+      }
     }
-    const int ix = (int)fmaxf(0.0f, fminf((float)(a.W - 1), px));
-    const int iy = (int)fmaxf(0.0f, fminf((float)(a.H - 1), py));
-    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)i;
-    atomicMin(&keys[(size_t)iy * a.W + ix], key);
+    unsigned long long* cell = &keys[(size_t)iy * a.W + ix];
+    if (a.winner == 0)
+      atomicMin(cell, ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)i);
+    else
+      atomicMax(cell, (unsigned long long)i + 1ull);
   }
 }
 
 __global__ __launch_bounds__(256) void proj_gather_kernel(const float* __restrict__ pts,
                                                           const unsigned long long* __restrict__ keys,
-                                                          int npix, float empty, float* __restrict__ image5,
-                                                          int32_t* __restrict__ proj_idx) {
+                                                          int npix, float* __restrict__ image,
+                                                          int32_t* __restrict__ proj_idx, const ProjArgs a) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
     const unsigned long long key = keys[i];
-    float o[5] = {empty, empty, empty, empty, empty};
+    float o[7] = {a.empty, a.empty, a.empty, a.empty, a.empty, 0.0f, 0.0f};
     int idx = -1;
-    if (key != ~0ull) {
-      idx = (int)(unsigned)(key & 0xffffffffull);
-      const f32x4 pt = *reinterpret_cast<const f32x4*>(pts + (size_t)idx * 4);
+    const bool hit = a.winner == 0 ? key != ~0ull : key != 0ull;
+    if (hit) {
+      idx = a.winner == 0 ? (int)(unsigned)(key & 0xffffffffull) : (int)(key - 1ull);
+      const float* pt = pts + (size_t)idx * a.stride;
       o[0] = pt[0]; o[1] = pt[1]; o[2] = pt[2]; o[3] = pt[3];
-      o[4] = __uint_as_float((unsigned)(key >> 32));
+      if (a.depth) o[4] = a.depth[idx];
+      else if (a.winner == 0) o[4] = __uint_as_float((unsigned)(key >> 32));
+      else {
+#pragma clang fp contract(off)
+        o[4] = sqrtf((pt[0] * pt[0] + pt[1] * pt[1]) + pt[2] * pt[2]);
+      }
+      o[6] = o[4] > 0.0f ? 1.0f : 0.0f;
     }
-#pragma unroll
-    for (int c = 0; c < 5; ++c) image5[(size_t)i * 5 + c] = o[c];
+    if (a.out_c > 5) {
+      int l = (hit && a.labels) ? a.labels[idx] : 0;   // empty pixels carry label 0 before the map
+      if (a.lut) l = (l >= 0 && l < a.lut_size) ? a.lut[l] : -1;
+      o[5] = (float)l;
+    }
+    for (int c = 0; c < a.out_c; ++c) image[(size_t)i * a.out_c + c] = o[c];
     if (proj_idx) proj_idx[i] = idx;
   }
 }

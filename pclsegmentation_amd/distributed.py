@@ -63,9 +63,10 @@ def broadcast_weights(spec, weights, src=0, device=None):
   if not dist.is_initialized() or dist.get_world_size() == 1:
     return weights
   n = sum(int(np.prod(w.shape)) for w in spec)
-  if device is None:
-    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" \
-      else torch.device("cpu")
+  if dist.get_backend() != "nccl":
+    device = torch.device("cpu")     # gloo moves host tensors (CPU tests, ranks sharing one GPU)
+  elif device is None:
+    device = torch.device("cuda", torch.cuda.current_device())
   if dist.get_rank() == src:
     blob = torch.from_numpy(pack_weights(spec, weights)).to(device)
   else:

@@ -34,7 +34,7 @@ EXPORTS = [
   "pclseg_set_stream", "pclseg_sync", "pclseg_host_alloc", "pclseg_host_free", "pclseg_forward", "pclseg_forward_raw",
   "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
   "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
-  "pclseg_op_confusion_matrix", "pclseg_op_project",
+  "pclseg_op_confusion_matrix", "pclseg_op_project", "pclseg_op_project_ex",
 ]
 
 
@@ -44,6 +44,18 @@ class Desc(ctypes.Structure):
               ("output_stride", ctypes.c_int32), ("device", ctypes.c_int32),
               ("micro_batch", ctypes.c_int32), ("flags", ctypes.c_uint32),
               ("mean", ctypes.c_double * 5), ("std", ctypes.c_double * 5)]
+
+
+PROJ_ROW_FOV, PROJ_ROW_RING = 0, 1
+PROJ_COL_FULL, PROJ_COL_FRONT = 0, 1
+PROJ_NEAREST, PROJ_LAST = 0, 1
+
+
+class ProjDesc(ctypes.Structure):
+  _fields_ = [("h", ctypes.c_int32), ("w", ctypes.c_int32), ("row_mode", ctypes.c_int32),
+              ("col_mode", ctypes.c_int32), ("winner", ctypes.c_int32), ("out_channels", ctypes.c_int32),
+              ("fov_up", ctypes.c_float), ("fov_down", ctypes.c_float), ("empty", ctypes.c_float),
+              ("left_phi", ctypes.c_double), ("right_phi", ctypes.c_double)]
 
 
 class PlanInfo(ctypes.Structure):
@@ -100,6 +112,8 @@ def load_library():
   lib.pclseg_op_confusion_matrix.argtypes = [vp, vp, ctypes.c_size_t, i32, vp, vp]
   lib.pclseg_op_project.argtypes = [vp, ctypes.c_size_t, i32, i32, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, vp, vp, vp, vp]
+  lib.pclseg_op_project_ex.argtypes = [ctypes.POINTER(ProjDesc), vp, i32, ctypes.c_size_t, vp, vp, vp, vp, i32,
+                                       vp, vp, vp, vp]
   for name in EXPORTS:
     fn = getattr(lib, name)
     if name not in ("pclseg_last_error", "pclseg_host_alloc"):
@@ -311,3 +325,21 @@ def op_project(points_dev, m, h, w, fov_up, fov_down, empty, image5_dev, proj_id
   check(load_library().pclseg_op_project(_ptr(points_dev), int(m), int(h), int(w), float(fov_up),
                                          float(fov_down), float(empty), _ptr(image5_dev),
                                          _ptr(proj_idx_dev), _ptr(scratch_dev), ctypes.c_void_p(stream or 0)))
+
+
+def make_proj_desc(h, w, row_mode=PROJ_ROW_FOV, col_mode=PROJ_COL_FULL, winner=PROJ_NEAREST, out_channels=5,
+                   fov_up=3.0, fov_down=-25.0, left_phi=0.0, right_phi=0.0, empty=0.0):
+  d = ProjDesc()
+  d.h, d.w, d.row_mode, d.col_mode, d.winner, d.out_channels = int(h), int(w), row_mode, col_mode, winner, out_channels
+  d.fov_up, d.fov_down, d.empty = float(fov_up), float(fov_down), float(empty)
+  d.left_phi, d.right_phi = float(left_phi), float(right_phi)
+  return d
+
+
+def op_project_ex(desc, points_dev, stride, m, ring_dev, depth_dev, labels_dev, lut_dev, image_dev, proj_idx_dev,
+                  scratch_dev, stream=0):
+  """Generalised projection (ring rows, front-view columns, last-point-wins, label / mask channels)."""
+  check(load_library().pclseg_op_project_ex(ctypes.byref(desc), _ptr(points_dev), int(stride), int(m), _ptr(ring_dev),
+                                            _ptr(depth_dev), _ptr(labels_dev), _ptr(lut_dev),
+                                            0 if lut_dev is None else int(lut_dev.numel()), _ptr(image_dev),
+                                            _ptr(proj_idx_dev), _ptr(scratch_dev), ctypes.c_void_p(stream or 0)))

@@ -1,0 +1,78 @@
+"""The N > 1 path with real engine ranks on the GPU.  The test box has ONE MI355X, so the two ranks
+share it and rendezvous over gloo (PCLSEG_DIST_BACKEND=gloo: RCCL cannot place two ranks on one
+device); everything else is the production path — fresh rank processes started by
+torch.distributed.run, one weight broadcast from rank 0, contiguous scan shards, no data-path
+collective, optional gather.  Each rank's result must be bit-identical to the single-process result
+for its shard (scans are independent: nets/SegmentationNetwork.py:133-136, BatchNorm in inference mode)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pclsegmentation_amd as P
+from pclsegmentation_amd import distributed as D
+from pclsegmentation_amd import engine as E
+from pclsegmentation_amd.utils.synthetic import synthetic_scans
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _rank_env():
+  env = dict(os.environ)
+  env.update(PCLSEG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+    env.pop(k, None)
+  return env
+
+
+def test_two_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path):
+  n, h, w = 7, 32, 240          # 7 scans over 2 ranks: shards [0,4) and [4,7)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+         os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(n), str(h), str(w)]
+  r = subprocess.run(cmd, env=_rank_env(), capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  # single-process reference on this process's engine
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2", height=h, width=w)
+  model.init_weights(4321)
+  raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=99)
+  eng = model.engine(h, w)
+  preds = np.empty((n, h, w), np.int32)
+  logits = np.empty((n, h, w, mc.NUM_CLASS), np.float32)
+  eng.forward_raw(raw, n, preds, None, logits, None, mem=E.MEM_HOST)
+  seen = np.zeros(n, bool)
+  for rank in range(2):
+    g = np.load(str(tmp_path / ("rank%d.npz" % rank)))
+    lo, hi = int(g["lo"]), int(g["hi"])
+    assert (lo, hi) == D.shard_range(n, rank, 2)
+    assert np.array_equal(g["preds"], preds[lo:hi]) and np.array_equal(g["logits"], logits[lo:hi])
+    seen[lo:hi] = True
+  assert seen.all()
+  assert np.array_equal(np.load(str(tmp_path / "gathered.npy")), preds)   # optional gather, scan order
+
+
+def test_bench_launches_its_own_ranks(cuda):
+  """`python bench.py --gpus 2` outside torchrun starts its rank processes itself (the driver's
+  launch line for N > 1 without torch.distributed.run) and prints ONE JSON line for the job."""
+  env = _rank_env()
+  env.pop("PCLSEG_DIST_BACKEND")      # bench.py chooses gloo itself when ranks outnumber GPUs
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+         "--workload", "ssv2_32x240", "--cpu-seconds", "0"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+  assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out

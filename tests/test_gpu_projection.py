@@ -11,16 +11,39 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _border_points(points, H, W, fov_up, fov_down):
+  """Points whose continuous image coordinates (float64) sit within a few float32 ulps of a cell
+  border: only for these can NumPy's float32 arctan2 / arcsin (not correctly rounded, platform
+  dependent) and the kernel's float64-then-round-once evaluation pick different cells."""
+  p = points.astype(np.float64)
+  depth = np.sqrt((p[:, :3] ** 2).sum(1))
+  up, down = fov_up / 180.0 * np.pi, fov_down / 180.0 * np.pi
+  cx = 0.5 * (-np.arctan2(p[:, 1], p[:, 0]) / np.pi + 1.0) * W
+  cy = (1.0 - (np.arcsin(p[:, 2] / depth) + abs(down)) / (abs(down) + abs(up))) * H
+  tol_x = 8 * np.spacing(np.float32(W))      # ~4 float32 operations on values up to W
+  tol_y = 8 * np.spacing(np.float32(H))
+  near = lambda c, tol: np.abs(c - np.round(c)) < tol
+  return near(cx, tol_x) | near(cy, tol_y)
+
+
 @pytest.mark.parametrize("name", ["kitti_64x1024", "small_32x256", "nuscenes_like_32x1024"])
 def test_projection_matches_reference(cuda, name):
   g = np.load(os.path.join(GOLDEN, "projection_%s.npz" % name))
-  scan = LaserScan(True, int(g["H"]), int(g["W"]), float(g["fov_up"]), float(g["fov_down"]))
+  H, W = int(g["H"]), int(g["W"])
+  scan = LaserScan(True, H, W, float(g["fov_up"]), float(g["fov_down"]))
   scan.set_points(g["points"][:, :3], g["points"][:, 3])
-  idx = scan.proj_idx
-  same = idx == g["proj_idx"]
-  # NumPy's float32 arctan2/arcsin are not correctly rounded everywhere; a point that sits within
-  # an ulp of a cell border may land in the neighbouring cell.  Everything else is exact.
-  assert same.mean() >= 0.9995, same.mean()
+  idx, gold = scan.proj_idx, g["proj_idx"]
+  same = idx == gold
+  # Index work is exact EXCEPT where a point sits on a cell border (see _border_points): the
+  # mismatching pixels are enumerated, each must involve such a border point, and there are few.
+  border = _border_points(g["points"], H, W, float(g["fov_up"]), float(g["fov_down"]))
+  bad = np.argwhere(~same)
+  print("%s: %d of %d pixels differ from the reference (%d border points in %d)"
+        % (name, len(bad), same.size, int(border.sum()), len(border)))
+  for y, x in bad:
+    winners = [i for i in (idx[y, x], gold[y, x]) if i >= 0]
+    assert any(border[i] for i in winners), ("non-border mismatch at", y, x, idx[y, x], gold[y, x])
+  assert len(bad) <= 2 * border.sum() and len(bad) <= 5e-4 * same.size
   assert np.array_equal(scan.proj_range[same], g["proj_range"][same])
   assert np.array_equal(scan.proj_xyz[same], g["proj_xyz"][same])
   assert np.array_equal(scan.proj_remission[same], g["proj_remission"][same])
@@ -29,6 +52,74 @@ def test_projection_matches_reference(cuda, name):
   pts = g["points"][idx[filled]]
   assert np.array_equal(scan.proj_xyz[filled], pts[:, :3])
   assert np.allclose(scan.proj_range[filled], np.linalg.norm(pts[:, :3], axis=1), rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["ring_32x1024", "ring_16x256"])
+def test_ring_projection_and_labels_match_reference(cuda, name):
+  """laserscan_nuscenes.py:191-223 (row = H-1-ring, the LAST point of a pixel wins) and the label
+  projection :377-383, against outputs of the reference's own code.  Rows are exact by
+  construction; columns can differ only for azimuth-border points (enumerated)."""
+  from pclsegmentation_amd.projection import SemLaserScan
+  g = np.load(os.path.join(GOLDEN, "projection2_%s.npz" % name))
+  H, W = int(g["H"]), int(g["W"])
+  scan = SemLaserScan(32, None, project=True, H=H, W=W, fov_up=10.0, fov_down=-30.0, use_ring_projection=True)
+  scan.set_points(g["points"][:, :3], g["points"][:, 3], g["ring"])
+  scan.set_label(g["labels"])
+  idx, gold = scan.proj_idx, g["proj_idx"]
+  same = idx == gold
+  p = g["points"].astype(np.float64)
+  cx = 0.5 * (-np.arctan2(p[:, 1], p[:, 0]) / np.pi + 1.0) * W
+  border = np.abs(cx - np.round(cx)) < 8 * np.spacing(np.float32(W))
+  bad = np.argwhere(~same)
+  print("%s: %d of %d pixels differ (%d border points)" % (name, len(bad), same.size, int(border.sum())))
+  for y, x in bad:
+    assert any(border[i] for i in (idx[y, x], gold[y, x]) if i >= 0)
+  assert len(bad) <= 2 * border.sum() + 1
+  assert np.array_equal(scan.proj_range[same], g["proj_range"][same])
+  assert np.array_equal(scan.proj_xyz[same], g["proj_xyz"][same])
+  assert np.array_equal(scan.proj_remission[same], g["proj_remission"][same])
+  assert np.array_equal(scan.proj_sem_label[same], g["proj_sem_label"][same])
+  assert np.array_equal(scan.proj_mask[same], g["proj_mask"][same])
+  # size-independent property: the winner of a pixel is the LAST point (highest index) of that
+  # pixel among the points the kernel itself placed there
+  filled = idx >= 0
+  assert np.array_equal(scan.proj_xyz[filled], g["points"][idx[filled], :3])
+  rows = (H - 1) - g["ring"]
+  assert np.array_equal(np.argwhere(filled)[:, 0], rows[idx[filled]])
+
+
+def test_label_map_and_converter_sample_match_reference(cuda):
+  """The converters' final [H,W,6] sample (semantic_kitti.py:160-171): xyz / remission / range with
+  empty pixels zeroed and the label channel passed through learning_map."""
+  from pclsegmentation_amd.projection import SemLaserScan
+  g = np.load(os.path.join(GOLDEN, "projection2_kitti_labels_32x512.npz"))
+  lm = {int(k): int(v) for k, v in zip(g["map_keys"], g["map_values"])}
+  scan = SemLaserScan(20, None, project=True, H=int(g["H"]), W=int(g["W"]), fov_up=float(g["fov_up"]),
+                      fov_down=float(g["fov_down"]))
+  scan.set_points(g["points"][:, :3], g["points"][:, 3])
+  scan.set_label(g["labels"].astype(np.int64), learning_map=lm)
+  same = scan.proj_idx == g["proj_idx"]
+  assert same.mean() > 0.999
+  final = scan.sample()
+  assert final.shape == g["final"].shape
+  assert np.array_equal(final[same].astype(np.float64), g["final"][same])
+
+
+def test_front_view_information_map_matches_reference(cuda):
+  """preprocessing/convert_validation_pcd_to_npy.py:97-156: front window, truncating column index,
+  out-of-window points dropped, ring rows, last point wins, 7 channels incl. mask = depth > 0."""
+  from pclsegmentation_amd.projection import pcl_xyz_i_r_d_l_to_information_map
+  f = np.load(os.path.join(GOLDEN, "projection2_front_32x240.npz"))
+  got = pcl_xyz_i_r_d_l_to_information_map(f["pcl"], H=32, W=240, C=7)
+  want = f["info"]
+  assert got.shape == want.shape and got.dtype == np.float64
+  diff = np.argwhere((got != want).any(-1))
+  # float64 atan2 on both sides: at most a handful of column-border points may differ by libm
+  print("front map: %d of %d pixels differ" % (len(diff), 32 * 240))
+  assert len(diff) <= 4
+  ok = ~(got != want).any(-1)
+  assert np.array_equal(got[ok], want[ok])
+  assert np.array_equal(got[..., 6], (got[..., 4] > 0).astype(np.float64))
 
 
 def test_nearest_point_wins_and_empty_value(cuda):

@@ -85,3 +85,24 @@ def test_projection_oracle_reproduces_reference_outputs(name):
   assert np.array_equal(idx, g["proj_idx"])
   assert np.array_equal(rng_, g["proj_range"]) and np.array_equal(xyz, g["proj_xyz"])
   assert np.array_equal(rem, g["proj_remission"])
+
+
+@pytest.mark.parametrize("name", ["ring_32x1024", "ring_16x256"])
+def test_ring_projection_oracle_reproduces_the_reference(name):
+  """tests/golden/projection2_ring_*.npz are outputs of the reference's own
+  LaserScan.do_range_projection_ring / SemLaserScan.do_label_projection."""
+  g = np.load(os.path.join(GOLDEN, "projection2_%s.npz" % name))
+  rng_, xyz, rem, idx, mask = O.range_projection_ring(g["points"], g["ring"], int(g["H"]), int(g["W"]))
+  assert np.array_equal(idx, g["proj_idx"]) and np.array_equal(rng_, g["proj_range"])
+  assert np.array_equal(xyz, g["proj_xyz"]) and np.array_equal(rem, g["proj_remission"])
+  assert np.array_equal(mask, g["proj_mask"])
+  assert np.array_equal(O.label_projection(idx, g["labels"]), g["proj_sem_label"])
+
+
+def test_label_projection_and_information_map_oracles_reproduce_the_reference():
+  g = np.load(os.path.join(GOLDEN, "projection2_kitti_labels_32x512.npz"))
+  lm = {int(k): int(v) for k, v in zip(g["map_keys"], g["map_values"])}
+  assert np.array_equal(O.label_projection(g["proj_idx"], g["labels"]), g["proj_sem_label"])
+  assert np.array_equal(O.label_projection(g["proj_idx"], g["labels"], lm), g["final"][..., 5])
+  f = np.load(os.path.join(GOLDEN, "projection2_front_32x240.npz"))
+  assert np.array_equal(O.information_map(f["pcl"]), f["info"])
