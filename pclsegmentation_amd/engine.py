@@ -184,6 +184,42 @@ def _ptr(x):
   return ctypes.c_void_p(x.data_ptr())  # torch.Tensor
 
 
+_NP_OF_TORCH = {"torch.float32": np.float32, "torch.int32": np.int32, "torch.uint8": np.uint8,
+                "torch.bool": np.uint8, "torch.int64": np.int64}
+
+
+def _checked(x, dtype, count, what, mem=None):
+  """Validate a buffer handed to the C ABI: dtype, C-contiguity, element count and, when ``mem`` is
+  given, that it lives on the side the call says (host array / CPU tensor vs CUDA tensor).  The
+  library reads ``count`` elements of ``dtype`` from the raw address: a float64 or strided array, or
+  a short buffer, would otherwise be read or written as garbage."""
+  if x is None:
+    return None
+  want = np.dtype(dtype)
+  if isinstance(x, np.ndarray):
+    if x.dtype != want or not x.flags["C_CONTIGUOUS"]:
+      raise ValueError("pclseg: %s must be a C-contiguous %s array, got %s%s" % (
+        what, want.name, x.dtype, "" if x.flags["C_CONTIGUOUS"] else " (not contiguous)"))
+    if x.size < count:
+      raise ValueError("pclseg: %s holds %d elements, the call needs %d" % (what, x.size, count))
+    if mem == MEM_DEVICE:
+      raise ValueError("pclseg: %s is a host array but the call was made with mem=MEM_DEVICE" % what)
+    return x
+  if hasattr(x, "data_ptr"):   # torch.Tensor
+    got = _NP_OF_TORCH.get(str(x.dtype))
+    if got is None or np.dtype(got).itemsize != want.itemsize or (np.dtype(got).kind == "f") != (want.kind == "f"):
+      raise ValueError("pclseg: %s must be a %s tensor, got %s" % (what, want.name, x.dtype))
+    if not x.is_contiguous():
+      raise ValueError("pclseg: %s must be contiguous" % what)
+    if x.numel() < count:
+      raise ValueError("pclseg: %s holds %d elements, the call needs %d" % (what, x.numel(), count))
+    if mem is not None and x.is_cuda != (mem == MEM_DEVICE):
+      raise ValueError("pclseg: %s lives on %s but the call was made with mem=%s" % (
+        what, "the device" if x.is_cuda else "the host", "MEM_DEVICE" if mem == MEM_DEVICE else "MEM_HOST"))
+    return x
+  return x   # raw integer address: the caller vouches for it
+
+
 class Engine:
   """One model graph on one device (wraps a pclseg_handle)."""
 
@@ -239,11 +275,26 @@ class Engine:
   def sync(self):
     check(self.lib.pclseg_sync(self._h), self._h)
 
+  def _px(self, n):
+    return int(n) * self.desc.height * self.desc.width
+
   def forward(self, lidar, mask, n, preds, probs=None, logits=None, mem=MEM_DEVICE):
+    px, nc = self._px(n), self.desc.num_class
+    _checked(lidar, np.float32, px * 6, "lidar", mem)
+    _checked(mask, np.uint8, px, "mask", mem)
+    _checked(preds, np.int32, px, "preds", mem)
+    _checked(probs, np.float32, px * nc, "probs", mem)
+    _checked(logits, np.float32, px * nc, "logits", mem)
     check(self.lib.pclseg_forward(self._h, _ptr(lidar), _ptr(mask), int(n), _ptr(preds),
                                   _ptr(probs), _ptr(logits), mem), self._h)
 
   def forward_raw(self, scans, n, preds, probs=None, logits=None, mask_out=None, mem=MEM_DEVICE):
+    px, nc = self._px(n), self.desc.num_class
+    _checked(scans, np.float32, px * 5, "scans", mem)
+    _checked(preds, np.int32, px, "preds", mem)
+    _checked(probs, np.float32, px * nc, "probs", mem)
+    _checked(logits, np.float32, px * nc, "logits", mem)
+    _checked(mask_out, np.uint8, px, "mask_out", mem)
     check(self.lib.pclseg_forward_raw(self._h, _ptr(scans), int(n), _ptr(preds), _ptr(probs),
                                       _ptr(logits), _ptr(mask_out), mem), self._h)
 

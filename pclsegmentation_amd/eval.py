@@ -1,6 +1,7 @@
 """Evaluation on the engine (reference: eval.py:33-82) — mIoU / IoU / recall / precision over a
-split of projected scans, with the confusion matrix accumulated ON THE DEVICE by
-``pclseg_op_confusion_matrix`` (exact int64 counts) right behind the forward pass.
+split of projected scans.  Each batch crosses PCIe ONCE (scans + labels up); the forward pass, the
+``label[~mask] = None`` step and the confusion-matrix accumulation (``pclseg_op_confusion_matrix``,
+exact int64 counts) all stay on the device, only the final [NC,NC] matrix comes back.
 
   python -m pclsegmentation_amd.eval -d <dataset dir> -i val -m squeezesegv2 -n squeezesegv2 -p model.npz
 
@@ -52,11 +53,14 @@ class MeanIoU:
     self._cm.zero_()
 
   def update_state(self, label, predictions):
+    """Host arrays or device tensors.  Labels outside [0, num_classes) are NOT counted (tf.metrics.
+    MeanIoU would raise for them): ``ignored`` keeps their running total so a caller can tell."""
     import torch
     lab = torch.as_tensor(np.asarray(label) if not hasattr(label, "is_cuda") else label)
     prd = torch.as_tensor(np.asarray(predictions) if not hasattr(predictions, "is_cuda") else predictions)
     lab = lab.to(self._dev, dtype=torch.int32).contiguous()
     prd = prd.to(self._dev, dtype=torch.int32).contiguous()
+    self._seen = getattr(self, "_seen", 0) + lab.numel()
     if lab.numel() != prd.numel():
       raise ValueError("label and predictions differ in size: %d vs %d" % (lab.numel(), prd.numel()))
     _engine.op_confusion_matrix(lab, prd, lab.numel(), self.num_classes, self._cm,
@@ -65,6 +69,11 @@ class MeanIoU:
   @property
   def total_cm(self):
     return self._cm.cpu().numpy()
+
+  @property
+  def ignored(self):
+    """Pixels whose label or prediction was outside [0, num_classes) and therefore not counted."""
+    return int(getattr(self, "_seen", 0) - int(self._cm.sum().item()))
 
   def result(self):
     cm = self.total_cm.astype(np.float64)
@@ -89,13 +98,16 @@ def evaluation(arg):
   none_index = config.CLASSES.index("None")
   miou_tracker = MeanIoU(num_classes=config.NUM_CLASS, name="MeanIoU")
   print("Performing Evaluation")
+  import torch
+  dev = torch.device("cuda", model.device)
   for b0 in range(0, len(files), arg.batch):
-    samples = [np.load(f).astype(np.float32) for f in files[b0:b0 + arg.batch]]
-    raw = np.stack([s[:, :, :5] for s in samples])
-    predictions, mask = model.predict_raw(raw, return_mask=True)
-    label = np.stack([s[:, :, 5] for s in samples]).astype(np.int32)
-    label[~mask] = none_index
-    miou_tracker.update_state(label, predictions.numpy())
+    samples = torch.from_numpy(np.stack([np.load(f).astype(np.float32) for f in files[b0:b0 + arg.batch]])).to(dev)
+    predictions, mask = model.predict_raw(samples[..., :5], return_mask=True)       # device tensors
+    label = torch.where(mask.bool(), samples[..., 5].to(torch.int32), torch.tensor(none_index, dtype=torch.int32, device=dev))
+    miou_tracker.update_state(label, predictions)
+  if miou_tracker.ignored:
+    print("warning: %d pixels carry a label outside [0, %d) and were not counted"
+          % (miou_tracker.ignored, config.NUM_CLASS))
   iou, recall, precision = confusion_matrix_to_iou_recall_precision(miou_tracker.total_cm)
   for i, cls in enumerate(config.CLASSES):
     print(cls.upper())
@@ -112,7 +124,7 @@ def main(argv=None):
   parser.add_argument("-d", "--data_path", type=str, required=True, help="Absolute path to the dataset")
   parser.add_argument("-i", "--image_set", type=str, default="val",
                       help="Default: `val`. But can also be train, val or test")
-  parser.add_argument("-t", "--eval_dir", type=str, default=None, help="(unused: no TensorBoard logs are written)")
+  parser.add_argument("-t", "--eval_dir", type=str, default=None, help="accepted for compatibility with the reference; unused (no TensorBoard logs are written)")
   parser.add_argument("-p", "--path_to_model", type=str, default=None, help="Path to the model: .npz file or reference SavedModel directory")
   parser.add_argument("-m", "--model", type=str, default="squeezesegv2",
                       help="Model name either `squeezesegv2`, `darknet53`, `darknet21`")

@@ -1,5 +1,6 @@
+#!/bin/bash
 # Round profile: tests, bench, rocprofv3 kernel stats and PMC traffic passes (separate runs).
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}; mkdir -p gpurun_out
 R=${1:-r01}
 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -3 > gpurun_out/${R}_pytest.log
 python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""OFF-BOX pin of the oracle against real TensorFlow (run where `tensorflow==2.9.1`, the
+reference's requirements.txt:1, is installed; it is NOT installable in the build image):
+
+    python tests/golden/make_tf_golden.py            # writes tests/golden/tf_*.npz and
+                                                     # tests/golden/tf_savedmodel_<arch>/
+
+What it does, using only THIS repository (never the reference's files):
+  1. builds each network as a tree of genuine Keras layers (Conv2D / Conv2DTranspose /
+     BatchNormalization / MaxPool2D / LeakyReLU / Softmax with padding="same", the arguments the
+     reference passes) whose ATTRIBUTE PATHS are the weight paths of nets/spec.py — the same paths a
+     reference model has ("fire2/squeeze", "enc3/residual_1/bn2", ...), so the object graph TensorFlow
+     writes into a SavedModel has the reference's shape;
+  2. loads the seeded synthetic weights (nets/weights.py, seed 4321) with layer.set_weights;
+  3. runs the committed golden inputs (tests/golden/model_*.npz: "raw") through
+     model([lidar, mask]) exactly as inference.py:47-78 does and stores TensorFlow's logits,
+     probabilities and predictions in tests/golden/tf_<case>.npz;
+  4. model.save()s each network (train.py:60) and copies variables/ + saved_model.pb next to the
+     vectors, giving tests/test_savedmodel.py a TensorFlow-WRITTEN bundle to read.
+
+Once those files are committed, tests/test_oracle_kat.py::test_oracle_matches_tensorflow and
+tests/test_savedmodel.py::test_reads_a_tensorflow_written_savedmodel stop skipping and the
+"PARITY UNPINNED" banners can go.  The walk below follows oracle/np_oracle.py (which cites the
+reference lines); only the primitives differ — here they are TensorFlow's.
+"""
+import glob
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import tensorflow as tf  # noqa: E402
+
+from pclsegmentation_amd import configs as C  # noqa: E402
+from pclsegmentation_amd.nets.weights import synthetic_weights, spec_for_config  # noqa: E402
+
+L = tf.keras.layers
+CASES = {  # golden file -> (arch, config)
+  "ssv2_32x240": ("squeezesegv2", C.SqueezeSegV2Config), "ssv2kitti_64x256": ("squeezesegv2", C.SqueezeSegV2KittiConfig),
+  "ssv2_real_32x240": ("squeezesegv2", C.SqueezeSegV2Config), "darknet21_32x240": ("darknet21", C.Darknet21),
+  "darknet53_32x240": ("darknet53", C.Darknet53), "darknet53kitti_16x64": ("darknet53", C.Darknet53Kitti),
+}
+
+
+class Node(L.Layer):
+  """A Keras layer that only holds children under the reference's attribute names."""
+
+
+def make_leaf(kind, shape, stride_w):
+  if kind == "conv":
+    kh, kw, _, cout = shape
+    return L.Conv2D(cout, (kh, kw), strides=(1, stride_w), padding="same", use_bias=True)
+  if kind == "conv_nobias":
+    kh, kw, _, cout = shape
+    return L.Conv2D(cout, (kh, kw), strides=(1, stride_w), padding="same", use_bias=False)
+  if kind == "deconv":
+    return L.Conv2DTranspose(shape[2], (1, 4), strides=(1, 2), padding="same")
+  if kind == "bn":
+    return L.BatchNormalization()   # epsilon 1e-3, the Keras default the reference relies on
+  raise ValueError(kind)
+
+
+class Net(tf.keras.Model):
+  """Layer tree built from the weight spec; call() walks it like the reference's call()."""
+
+  def __init__(self, arch, mc, spec, strides):
+    super().__init__()
+    self.arch, self.mc = arch, mc
+    self.softmax = L.Softmax(axis=-1)
+    self.leaky = L.LeakyReLU(0.1)
+    groups = {}
+    for w in spec:
+      prefix, leaf = w.path.rsplit("/", 1)
+      groups.setdefault(prefix, {})[leaf] = w
+    self._leaves = {}
+    for prefix, members in groups.items():
+      if "gamma" in members:
+        kind, shape = "bn", members["gamma"].shape
+      elif members["kernel"].kind == "deconv":
+        kind, shape = "deconv", members["kernel"].shape
+      else:
+        kind, shape = ("conv" if "bias" in members else "conv_nobias"), members["kernel"].shape
+      parts = prefix.split("/")
+      node = self
+      for part in parts[:-1]:      # "enc3/residual_1/bn2" -> self.enc3.residual_1.bn2, like the reference's attributes
+        if not hasattr(node, part):
+          setattr(node, part, Node(name=part))
+        node = getattr(node, part)
+      layer = make_leaf(kind, shape, strides.get(prefix, 1))
+      setattr(node, parts[-1], layer)
+      self._leaves[prefix] = (layer, kind, members)
+
+  def lay(self, prefix):
+    return self._leaves[prefix][0]
+
+  def load(self, weights):
+    for prefix, (layer, kind, members) in self._leaves.items():
+      if kind == "bn":
+        vals = [weights[prefix + "/" + k] for k in ("gamma", "beta", "moving_mean", "moving_variance")]
+      else:
+        vals = [weights[prefix + "/kernel"]] + ([weights[prefix + "/bias"]] if "bias" in members else [])
+      layer.set_weights([np.asarray(v, np.float32) for v in vals])
+
+  # ---- SqueezeSegV2 (oracle/np_oracle.py: cam, fire, squeezesegv2_logits)
+  def cam(self, x, p):
+    pool = tf.nn.max_pool2d(x, ksize=7, strides=1, padding="SAME")
+    sq = tf.nn.relu(self.lay(p + "/squeeze_bn")(self.lay(p + "/squeeze")(pool), training=False))
+    ex = tf.nn.sigmoid(self.lay(p + "/excitation_bn")(self.lay(p + "/excitation")(sq), training=False))
+    return x * ex
+
+  def fire(self, x, p, up=False):
+    sq = tf.nn.relu(self.lay(p + "/squeeze_bn")(self.lay(p + "/squeeze")(x), training=False))
+    if up:
+      sq = tf.nn.relu(self.lay(p + "/upconv")(sq))
+    e1 = tf.nn.relu(self.lay(p + "/expand1x1_bn")(self.lay(p + "/expand1x1")(sq), training=False))
+    e3 = tf.nn.relu(self.lay(p + "/expand3x3_bn")(self.lay(p + "/expand3x3")(sq), training=False))
+    return tf.concat([e1, e3], axis=3)
+
+  def ssv2(self, x_in):
+    x = tf.nn.relu(self.lay("bn1")(self.lay("conv1")(x_in), training=False))
+    cam1 = self.cam(x, "cam1")
+    skip = self.lay("bn1_skip")(self.lay("conv1_skip")(x_in), training=False)
+    pool = lambda t: tf.nn.max_pool2d(t, ksize=3, strides=[1, 1, 2, 1], padding="SAME")
+    x = self.fire(pool(cam1), "fire2")
+    x = self.fire(self.cam(x, "cam2"), "fire3")
+    cam3 = self.cam(x, "cam3")
+    x = self.fire(pool(cam3), "fire4")
+    fire5 = self.fire(x, "fire5")
+    x = pool(fire5)
+    for p in ("fire6", "fire7", "fire8", "fire9"):
+      x = self.fire(x, p)
+    x = self.fire(x, "fire10", True) + fire5
+    x = self.fire(x, "fire11", True) + cam3
+    x = self.fire(x, "fire12", True) + cam1
+    x = self.fire(x, "fire13", True) + skip
+    return self.lay("conv14")(x)
+
+  # ---- Darknet (oracle/np_oracle.py: basic_block, darknet_logits)
+  def block(self, x, p):
+    y = self.leaky(self.lay(p + "/bn1")(self.lay(p + "/conv1")(x), training=False))
+    y = self.leaky(self.lay(p + "/bn2")(self.lay(p + "/conv2")(y), training=False))
+    return y + x
+
+  def darknet(self, x):
+    from oracle.np_oracle import darknet_strides, DARKNET_BLOCKS   # stride/skip logic is integer code
+    enc_s, dec_s = darknet_strides(self.mc.get("OUTPUT_STRIDE", 16))
+    blocks = DARKNET_BLOCKS[self.mc.NUM_LAYERS]
+    skips, os_ = {}, 1
+    x = self.leaky(self.lay("bn1")(self.lay("conv1")(x), training=False))
+    for i in range(5):
+      p = "enc%d" % (i + 1)
+      y = self.leaky(self.lay(p + "/bn1")(self.lay(p + "/conv1")(x), training=False))
+      for j in range(blocks[i]):
+        y = self.block(y, "%s/residual_%d" % (p, j))
+      if y.shape[2] < x.shape[2]:
+        skips[os_] = x
+        os_ *= 2
+      x = y
+    for k in range(5):
+      p = "dec%d" % (5 - k)
+      y = self.lay(p + ("/upconv1" if dec_s[k] == 2 else "/conv1"))(x)
+      y = self.block(self.leaky(self.lay(p + "/bn1")(y, training=False)), p + "/block")
+      if y.shape[2] > x.shape[2]:
+        os_ //= 2
+        y = y + skips[os_]
+      x = y
+    return self.lay("head")(x)
+
+  def call(self, inputs, training=False, mask=None):
+    lidar, lidar_mask = inputs[0], inputs[1]
+    logits = self.ssv2(lidar) if self.arch == "squeezesegv2" else self.darknet(lidar)
+    prob = self.softmax(logits)
+    pred = tf.argmax(prob, axis=-1, output_type=tf.int32)
+    pred = tf.where(lidar_mask, pred, tf.ones_like(pred) * self.mc.CLASSES.index("None"))
+    self.last_logits = logits
+    return prob, pred
+
+
+def strides_for(arch, mc):
+  """W strides of the strided convolutions, by weight-path prefix."""
+  if arch == "squeezesegv2":
+    return {"conv1": 2}
+  from oracle.np_oracle import darknet_strides
+  enc_s, _ = darknet_strides(mc.get("OUTPUT_STRIDE", 16))
+  return {"enc%d/conv1" % (i + 1): s for i, s in enumerate(enc_s)}
+
+
+def main():
+  saved = set()
+  for case, (arch, cfg) in CASES.items():
+    path = os.path.join(HERE, "model_%s.npz" % case)
+    if not os.path.exists(path):
+      continue
+    g = np.load(path)
+    mc = cfg()
+    spec = spec_for_config(arch, mc)
+    weights = synthetic_weights(spec)
+    net = Net(arch, mc, spec, strides_for(arch, mc))
+    raw = g["raw"].astype(np.float32)
+    # the caller-side pre-processing of inference.py:47-62, in NumPy like the reference
+    mask = raw[..., 4] > 0
+    lidar = (raw - np.asarray(mc.INPUT_MEAN, np.float64).reshape(5)) / np.asarray(mc.INPUT_STD, np.float64).reshape(5)
+    lidar[~mask] = 0.0
+    lidar = np.append(lidar, mask[..., None].astype(lidar.dtype), axis=-1)
+    net([tf.constant(lidar[:1].astype(np.float32)), tf.constant(mask[:1])])     # build the variables
+    net.load(weights)
+    prob, pred = net([tf.constant(lidar.astype(np.float32)), tf.constant(mask)])
+    np.savez_compressed(os.path.join(HERE, "tf_%s.npz" % case), logits=net.last_logits.numpy(),
+                        probabilities=prob.numpy(), predictions=pred.numpy(), tf_version=tf.__version__)
+    print(case, "max |tf - oracle| logits = %.3g" % np.abs(net.last_logits.numpy() - g["logits"]).max(),
+          "class ids equal on decided pixels:", bool(np.array_equal(pred.numpy()[g["margin"] > 2e-3],
+                                                                    g["preds"][g["margin"] > 2e-3])))
+    key = (arch, mc.NUM_CLASS, mc.get("NUM_LAYERS"))
+    if key not in saved and raw.shape[1] * raw.shape[2] <= 32 * 240:
+      saved.add(key)
+      out = os.path.join(HERE, "tf_savedmodel_%s_nc%d" % (arch, mc.NUM_CLASS))
+      tmp = out + "_full"
+      net.save(tmp)                                    # what the reference's train.py:60 does
+      shutil.rmtree(out, ignore_errors=True)
+      os.makedirs(out)
+      shutil.copytree(os.path.join(tmp, "variables"), os.path.join(out, "variables"))
+      shutil.copy(os.path.join(tmp, "saved_model.pb"), out)
+      shutil.rmtree(tmp)
+      print("saved", out, sum(os.path.getsize(f) for f in glob.glob(out + "/**/*", recursive=True) if os.path.isfile(f)), "bytes")
+
+
+if __name__ == "__main__":
+  main()

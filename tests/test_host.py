@@ -176,3 +176,25 @@ def test_tf_exporter_walks_reference_attribute_paths(tmp_path):
   del root.fire9.expand3x3_bn.moving_variance
   with pytest.raises(ValueError, match="fire9.expand3x3_bn.moving_variance"):
     collect_weights(root, spec)
+
+
+def test_engine_rejects_mistyped_or_short_buffers():
+  """The C ABI reads raw addresses: float64 / strided / short / wrong-side buffers must be refused in
+  Python (ValueError) before they reach it.  Needs no GPU: the check runs before the call."""
+  from pclsegmentation_amd.engine import _checked, MEM_HOST, MEM_DEVICE
+  import torch
+  ok = np.zeros((2, 4, 8, 5), np.float32)
+  assert _checked(ok, np.float32, ok.size, "scans", MEM_HOST) is ok
+  for bad in (ok.astype(np.float64), ok[:, :, ::2], ok[:1]):
+    with pytest.raises(ValueError):
+      _checked(bad, np.float32, ok.size, "scans", MEM_HOST)
+  with pytest.raises(ValueError):
+    _checked(ok, np.float32, ok.size, "scans", MEM_DEVICE)          # host array, device call
+  t = torch.zeros((2, 4, 8), dtype=torch.int32)
+  assert _checked(t, np.int32, t.numel(), "preds", MEM_HOST) is t
+  with pytest.raises(ValueError):
+    _checked(t.to(torch.int64), np.int32, t.numel(), "preds", MEM_HOST)
+  with pytest.raises(ValueError):
+    _checked(t.transpose(0, 2), np.int32, t.numel(), "preds", MEM_HOST)
+  with pytest.raises(ValueError):
+    _checked(t, np.int32, t.numel(), "preds", MEM_DEVICE)

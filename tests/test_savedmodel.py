@@ -105,3 +105,30 @@ def test_savedmodel_errors_name_the_tensor(tmp_path):
   _make_savedmodel(root2, spec, wrong)
   with pytest.raises(ValueError, match="shape"):
     SM.load_savedmodel_weights(root2, spec)
+
+
+# ---- a TensorFlow-WRITTEN bundle (tests/golden/tf_savedmodel_*, made off-box by make_tf_golden.py)
+import glob as _glob
+
+_TF_DIRS = sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_savedmodel_*")))
+
+
+@pytest.mark.skipif(not _TF_DIRS, reason="reader parity unpinned: no TensorFlow-written SavedModel committed yet "
+                    "(tests/golden/tf_savedmodel_*; generate with tests/golden/make_tf_golden.py where TF 2.9 runs)")
+@pytest.mark.parametrize("path", _TF_DIRS, ids=[os.path.basename(p) for p in _TF_DIRS])
+def test_reads_a_tensorflow_written_savedmodel(path):
+  """Every tensor of the seeded weight set comes back bit-identical from a bundle TensorFlow wrote,
+  found through the reference's attribute paths whichever checkpoint-key scheme TF used."""
+  import pclsegmentation_amd as P
+  from pclsegmentation_amd import savedmodel as SM
+  from pclsegmentation_amd.nets.weights import synthetic_weights
+  arch, nc = os.path.basename(path)[len("tf_savedmodel_"):].rsplit("_nc", 1)
+  config = {("squeezesegv2", "11"): "squeezesegv2", ("squeezesegv2", "20"): "squeezesegv2kitti",
+            ("darknet21", "11"): "darknet21", ("darknet53", "11"): "darknet53",
+            ("darknet53", "20"): "darknet53kitti"}[(arch, nc)]
+  mc, model = P.load_model_config(arch, config)
+  spec = model.weight_spec()
+  want = synthetic_weights(spec)
+  got = SM.load_savedmodel_weights(path, spec)
+  for w in spec:
+    assert np.array_equal(got[w.path], want[w.path]), w.path
