@@ -371,6 +371,10 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
   if (pair) {
     static const int wt = getenv("PCLSEG_WT") ? atoi(getenv("PCLSEG_WT")) : 1;
+    // half of the blocks of an 8-wave pair take the 1x1 half first (fire8/9/10: -1.3 .. -3.4 us; the
+    // 4-wave pairs measured neutral to worse)
+    static const int flip = getenv("PCLSEG_FLIP") ? atoi(getenv("PCLSEG_FLIP")) : 3;
+    a.flip_bit = op.nw == 8 ? flip : -1;
     a.wt = (wt && !a.res1 && op.nw == 4) ? 1 : 0;   // pays for the 4-wave pairs that only write (see store_quad)
     return launch_conv_pair(op, epi, grid, lds, s, a);
   }

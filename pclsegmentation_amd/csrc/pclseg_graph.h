@@ -198,7 +198,8 @@ inline void op_geometry(Op* op) {
   // f16 mode: 40 KiB keeps four blocks per CU resident (160 KiB LDS); worth a second channel chunk
   // from 64 input channels up (head 77 -> 68 us), not for the 48-channel squeezes (35 -> 36 us).
   // Merged FIRE pairs and 8-wave blocks take the whole patch in one chunk.
-  const int64_t budget16 = (op->cin_t >= 64 && !op->pair && op->nw == 4) ? 40 * 1024 : budget;
+  static const int64_t b64 = getenv("PCLSEG_LDS_BUDGET64") ? atoi(getenv("PCLSEG_LDS_BUDGET64")) : 40 * 1024;   // tuning aid
+  const int64_t budget16 = (op->cin_t >= 64 && !op->pair && op->nw == 4) ? b64 : budget;
   op->ck16 = 64;
   while (op->ck16 > 16 && lds_bytes_f16(*op, op->ck16) > budget16) op->ck16 /= 2;
   op->ck32 = 32;

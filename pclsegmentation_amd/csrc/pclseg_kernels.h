@@ -78,6 +78,7 @@ struct ConvArgs {
   int out_s16;  // write the output in split-f16 pair format
   unsigned* range_flag;  // sticky: set when a value that is split to f16 hi/lo has |v| >= 65504
   int wt;                // write-through output stores (see store_quad)
+  int flip_bit;          // merged pairs: blocks with this bit of blockIdx.x set run the 1x1 half first (-1: none)
   int skw_lds_off;       // byte offset of the fused skip branch's [9][out_C] weights in dynamic LDS
   ConvSub sub[2];
 };
@@ -626,9 +627,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       // on every launch)
       stage(0, cin8);
       __syncthreads();
+      // Every block of a launch starts at the same time; if all of them ran 3x3 -> store -> 1x1 ->
+      // store in the same order, the whole chip would alternate between a matrix-core phase (HBM
+      // idle) and a store burst (matrix cores idle).  Half of the blocks therefore take the halves in
+      // the opposite order, so one half's stores coincide with the other half's K loop.
+      const int flip = a.flip_bit >= 0 ? (int)((blockIdx.x >> a.flip_bit) & 1u) : 0;
 #pragma nounroll
       for (int half = 0; half < 2; ++half) {
-        const ConvSub& K = a.sub[1 - half];
+        const ConvSub& K = a.sub[(1 - half) ^ flip];
         if (half) {
 #pragma unroll
           for (int m = 0; m < MTW; ++m)
