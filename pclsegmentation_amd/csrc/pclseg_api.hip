@@ -192,6 +192,38 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
   }
 }
 
+// fused next-squeeze fragments (conv_kernel FSQ).  After a half (sidx: 0 = expand1x1, 1 = expand3x3)
+// lane (p, g) of the wave that owns cout group cg holds, per pixel, channels 4g..4g+3 of its tiles
+// 2st and 2st+1: k-slot (g, j) of partial-GEMM step st is channel
+//   c = co_off(half) + (cg*ntw + 2st + (j >> 2))*16 + 4g + (j & 3)      (zero if that tile does not exist).
+// A-fragment lane (r = lane & 15, g = lane >> 4), element j = BN-folded squeeze weight W[c][16qt + r].
+void pack_fsq(const Op& op, const FoldIn& f, const std::vector<double>& scale, _Float16* dst) {
+  const SubOp& sq = op.fsq;
+  const int ncg = op.sub[0].nctp / op.ntw, ns = (op.ntw + 1) / 2, nq = sq.nctp;
+  const int cx = op.sub[0].cout + op.sub[1].cout;   // channels of the (never materialised) pair output
+  for (int half = 0; half < 2; ++half)
+    for (int cg = 0; cg < ncg; ++cg)
+      for (int st = 0; st < ns; ++st)
+        for (int qt = 0; qt < nq; ++qt) {
+          _Float16* blk = dst + ((((size_t)half * ncg + cg) * ns + st) * nq + qt) * 1024;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 15, gg = lane >> 4, q = qt * 16 + r;
+            for (int j = 0; j < 8; ++j) {
+              const int nn = 2 * st + (j >> 2);
+              const int cl = (cg * op.ntw + nn) * 16 + 4 * gg + (j & 3);   // channel within the half
+              float w = 0.0f;
+              if (nn < op.ntw && cl < op.sub[half].cout && q < sq.cout) {
+                const int c = op.sub[half].co_off + cl;
+                if (c < cx) w = (float)((double)f.kernel[(size_t)c * sq.cout + q] * scale[q]);
+              }
+              const _Float16 hi = (_Float16)w;
+              blk[lane * 8 + j] = hi;
+              blk[512 + lane * 8 + j] = (_Float16)(w - (float)hi);
+            }
+          }
+        }
+}
+
 // ---- launch helpers -------------------------------------------------------------------------
 template <int MTW, int NTW, int WN, bool HEAD, bool F16, bool PAIR = false, int NW = 4>
 hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
@@ -235,14 +267,38 @@ hipError_t launch_conv_cfg(int mtw, int ntw, int wn, int epi, dim3 grid, size_t 
 
 // merged FIRE expand pair (split-f16 mode): the block shapes the reference's FIRE sizes use
 // (pclseg_graph.h: pair_geometry); (mtw, ntw, wn, nw)
-#define PCLSEG_PAIR_CFGS(X) X(4, 2, 2, 4) X(4, 2, 1, 4) X(8, 2, 8, 8) X(4, 3, 4, 8) X(4, 2, 4, 8) X(4, 2, 2, 8)
+#define PCLSEG_PAIR_CFGS(X) X(4, 2, 2, 4) X(4, 2, 1, 4) X(8, 2, 8, 8) X(4, 3, 4, 8) X(4, 2, 4, 8) X(4, 2, 2, 8) X(4, 2, 8, 8) X(2, 3, 4, 8) X(4, 1, 8, 8)
 inline bool pair_cfg_ok(const Op& op) {
   if (op.sub[0].nctp != op.sub[1].nctp || op.ck16 < op.cin_t) return false;
+  if (op.fsq_fused) return true;   // its shapes are PCLSEG_FSQ_CFGS (launch_conv_fsq)
 #define PCLSEG_X(M_, N_, W_, NW_) if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == NW_) return true;
   PCLSEG_PAIR_CFGS(PCLSEG_X)
 #undef PCLSEG_X
   return false;
 }
+// merged pair + fused next squeeze: (mtw, ntw, wn, nq) of fire8/9 (256+256 -> 64), fire6 (192+192 -> 48),
+// fire7 (192+192 -> 64), fire4 (128+128 -> 32); 8 waves, 64-pixel tiles
+#define PCLSEG_FSQ_CFGS(X) X(4, 2, 8, 4) X(2, 3, 4, 3) X(2, 3, 4, 4) X(4, 1, 8, 2)
+hipError_t launch_conv_fsq(const Op& op, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+#define PCLSEG_X(M_, N_, W_, Q_) \
+  if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16) { \
+    auto kfn = conv_kernel<M_, N_, W_, false, true, 0, true, 8, Q_>; \
+    if (lds > 64 * 1024) { \
+      static bool raised = false;   /* once per kernel: dynamic LDS beyond the 64 KiB default */ \
+      if (!raised) { \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (e != hipSuccess) return e; \
+        raised = true; \
+      } \
+    } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a); \
+    return hipGetLastError(); \
+  }
+  PCLSEG_FSQ_CFGS(PCLSEG_X)
+#undef PCLSEG_X
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_conv_pair(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
 #define PCLSEG_X(M_, N_, W_, NW_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == NW_) \
@@ -349,7 +405,11 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   lds = (lds + 15) & ~(size_t)15;
   a.skw_lds_off = (int)lds;
   if (a.skx) lds += (size_t)9 * a.out_C * sizeof(float);   // fused skip branch weights behind the patch
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
+    if (exact) return hipErrorInvalidValue;
+    lds = std::max(lds, (size_t)8 * op.mtw * 16 * op.fsq.nctp * 16 * sizeof(float));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+  } else if (lds > 64 * 1024) return hipErrorInvalidValue;
   // (the fused-skip-branch epilogue of fire13 needs more registers than the merged kernel has left)
   const bool pair = !exact && op.pair && pair_cfg_ok(op) && !a.skx && !a.res2;
   if (pair) {  // one block = cout group of the 3x3 half + the same group of the 1x1 half
@@ -369,6 +429,15 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
+  if (op.fsq_fused) {
+    if (!pair) return hipErrorInvalidValue;
+    a.fsq_w16 = w16 + op.fsq.w16_off;
+    a.fsq_bias = bias + op.fsq.b_off;
+    a.fsq_q = op.fsq.nctp * 16;
+    a.fsq_ncg = op.sub[0].nctp / op.ntw;
+    a.flip_bit = -1;
+    return launch_conv_fsq(op, grid, lds, s, a);
+  }
   if (pair) {
     static const int wt = getenv("PCLSEG_WT") ? atoi(getenv("PCLSEG_WT")) : 1;
     // half of the blocks of an 8-wave pair take the 1x1 half first (fire8/9/10: -1.3 .. -3.4 us; the
@@ -475,7 +544,10 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
       if (op.res2 >= 0) { a.res2 = arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
       if (op.sk_in >= 0) { a.skx = arena + g.tensors[op.sk_in].offset; a.skw = h->d_bias + op.sk.b_off; }
     }
-    HIP_TRY(h, launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream));
+    const hipError_t le = launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream);
+    if (le != hipSuccess)
+      return fail(h, PCLSEG_ERR_HIP, fmt("launch of '%s' failed (%s): block shape mtw=%d ntw=%d wn=%d nw=%d, pair=%d, fused squeeze=%d",
+                                         op.name().c_str(), hipGetErrorString(le), op.mtw, op.ntw, op.wn, op.nw, (int)op.pair, (int)op.fsq_fused));
   }
   return PCLSEG_OK;
 }
@@ -946,6 +1018,19 @@ int pclseg_finalize(pclseg_handle* h) {
           dst[(size_t)ci * su.cout + co] =
               ci < cin ? (float)((double)f.kernel[(size_t)ci * su.cout + co] * scale[co]) : 0.0f;
       for (int co = 0; co < su.cout; ++co) dst[(size_t)8 * su.cout + co] = (float)shift[co];
+    }
+    if (op.fsq_fused) {
+      const SubOp& su = op.fsq;
+      FoldIn f;
+      f.kernel = W(su.name + "/kernel"); f.bias = W(su.name + "/bias");
+      f.gamma = W(su.bn + "/gamma"); f.beta = W(su.bn + "/beta");
+      f.mean = W(su.bn + "/moving_mean"); f.var = W(su.bn + "/moving_variance");
+      if (!f.kernel || !f.bias || !f.gamma || !f.beta || !f.mean || !f.var)
+        return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", su.name.c_str()));
+      std::vector<double> scale, shift;
+      fold_bn(su, f, &scale, &shift);
+      pack_bias(su, shift, bias.data() + su.b_off);
+      pack_fsq(op, f, scale, w16.data() + su.w16_off);
     }
     for (int i = 0; i < op.nsub; ++i) {
       const SubOp& su = op.sub[i];

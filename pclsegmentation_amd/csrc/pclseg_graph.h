@@ -82,6 +82,10 @@ struct Op {
   int ck32 = 32;         // channels per LDS pass, exact-f32 mode
   int pool_kh = 1, pool_kw = 1;
   bool pair = false;     // FIRE expand pair run as merged blocks (conv_kernel PAIR), split-f16 mode
+  // fused squeeze of the NEXT FIRE module (conv_kernel FSQ): this op writes fireN+1/squeeze instead
+  // of its own output; `fsq` names the Keras tensors, fsq.w16_off / b_off locate the packed fragments
+  bool fsq_fused = false;
+  SubOp fsq;
   // optional fused skip branch (SqueezeSegV2 conv1_skip/bn1_skip): BN(conv1x1(sk_in)) is added
   // in the epilogue; `sk` names its Keras tensors, sk.b_off locates [8][C] weights + [C] bias
   int sk_in = -1;
@@ -180,7 +184,14 @@ inline void op_geometry(Op* op) {
   op->mtw = (op->wn == 1 && op->nsub == 1 && op->ntw != 1) ? 2 : 4;
   op->nw = 4;
   if (op->pair) pair_geometry(op);
-  if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw[,nw];subname=..."
+  static const int geom_only = getenv("PCLSEG_FSQ_GEOM_ONLY") ? atoi(getenv("PCLSEG_FSQ_GEOM_ONLY")) : 0;   // debug
+  if (op->fsq_fused || (geom_only && op->pair && (nct == 16 || nct == 12 || nct == 8) && op->res1 < 0)) {   // 8 waves on a 64-pixel tile, all couts of both halves in the block
+    op->nw = 8;
+    if (nct == 16) { op->wn = 8; op->ntw = 2; op->mtw = 4; }
+    else if (nct == 12) { op->wn = 4; op->ntw = 3; op->mtw = 2; }
+    else { op->wn = 8; op->ntw = 1; op->mtw = 4; }
+  }
+  if (!op->fsq_fused) if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw[,nw];subname=..."
     const std::string key = op->sub[0].name + "=";
     const char* hit = strstr(ov, key.c_str());
     int a = 0, b = 0, c = 0, d = 4;
@@ -209,6 +220,11 @@ inline void op_geometry(Op* op) {
 
 inline int64_t sub_w32_floats(const Op& op, const SubOp& s) {
   return (int64_t)s.nkh * s.nkw * ((op.cin_t + 15) / 16) * s.nctp * 256;
+}
+// fused next-squeeze fragments: [half][cout group][K-step of two cout tiles][16-q tile][hi|lo][lane][8]
+inline int64_t fsq_w16_halfs(const Op& op) {
+  const int ncg = op.sub[0].nctp / op.ntw, ns = (op.ntw + 1) / 2, nq = (op.fsq.cout + 15) / 16;
+  return (int64_t)2 * ncg * ns * nq * 1024;
 }
 inline int f16_steps_full(const Op& op, const SubOp& s) { return (s.nkh * s.nkw * (op.ck16 / 8) + 3) / 4; }
 inline int f16_chunks(const Op& op) { return ((op.cin_t + 7) / 8 + op.ck16 / 8 - 1) / (op.ck16 / 8); }
@@ -442,13 +458,36 @@ inline void build_squeezesegv2(Graph* g) {
     return out;
   };
   int last_expand = -1;
+  // fireN's expand output feeds ONLY fireN+1's squeeze for N = 4, 6, 7, 8, 9 (:302-312): there the
+  // squeeze is computed by fireN's expand blocks and the expand output is never written (split-f16
+  // arithmetic only; every intermediate stays observable with KEEP_ACTIVATIONS, which disables it)
+  static const int fuse_env = getenv("PCLSEG_FUSE_SQ") ? atoi(getenv("PCLSEG_FUSE_SQ")) : 1;
+  static const int fuse_keep = getenv("PCLSEG_FUSE_KEEP") ? atoi(getenv("PCLSEG_FUSE_KEEP")) : 0;   // debug
+  const bool fuse = fuse_env && !(g->desc.flags & (PCLSEG_FLAG_EXACT_F32 | PCLSEG_FLAG_RANGE_FALLBACK)) &&
+                    (fuse_keep || !(g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS));
   auto fire = [&](const std::string& p, int x, int sq_c, int e1, int e3, bool up, int skip,
-                  int64_t skip_floats = 0) {
-    int s = b.conv(p + "/squeeze", x, 1, 1, sq_c, 1, true, p + "/squeeze_bn", 1);
+                  int64_t skip_floats = 0, bool fuse_prev = false) {
+    int s;
+    static const int fuse_mask = getenv("PCLSEG_FUSE_MASK") ? atoi(getenv("PCLSEG_FUSE_MASK")) : 255;   // debug: bit per fusion
+    const int fuse_bit = p == "fire5" ? 1 : p == "fire7" ? 2 : p == "fire8" ? 4 : p == "fire9" ? 8 : 16;
+    if (fuse_prev && fuse && (fuse_mask & fuse_bit) && last_expand >= 0 && g->ops[last_expand].out == x) {
+      const TensorInfo tx = g->tensors[x];
+      Op& pe = g->ops[last_expand];
+      pe.fsq = b.conv_sub(p + "/squeeze", 1, 1, tx.C, sq_c, true, p + "/squeeze_bn", 1, 0);
+      pe.fsq_fused = true;
+      s = b.tensor(p + "/squeeze", tx.H, tx.W, sq_c);
+      pe.out = s;
+      b.touch(s, last_expand);
+      g->tensors[x].def_op = g->tensors[x].last_op = -1;   // never materialised
+      g->alg_macs += (int64_t)tx.H * tx.W * tx.C * sq_c;
+    } else {
+      s = b.conv(p + "/squeeze", x, 1, 1, sq_c, 1, true, p + "/squeeze_bn", 1);
+    }
+    const int64_t in_floats = b.fl(x);
     if (up) s = b.deconv(p + "/upconv", s, sq_c, "", 1);  // ReLU, no BN (:194)
     const int out = b.tensor(p, g->tensors[s].H, g->tensors[s].W, e1 + e3);
     last_expand = b.expand_pair(p, s, e1, e3, out, skip);
-    b.module_bytes(b.fl(x) + (skip >= 0 ? b.fl(skip) : skip_floats), b.fl(out));
+    b.module_bytes(in_floats + (skip >= 0 ? b.fl(skip) : skip_floats), b.fl(out));
     return out;
   };
   auto pool = [&](const std::string& p, int x) {
@@ -472,13 +511,13 @@ inline void build_squeezesegv2(Graph* g) {
   const int cam3 = cam("cam3", x);                                                          // :299
   x = pool("pool3", cam3);                                                                  // :301
   x = fire("fire4", x, 32, 128, 128, false, -1);
-  const int fire5 = fire("fire5", x, 32, 128, 128, false, -1);                              // :303
+  const int fire5 = fire("fire5", x, 32, 128, 128, false, -1, 0, true);                     // :303
   x = pool("pool5", fire5);                                                                 // :305
   x = fire("fire6", x, 48, 192, 192, false, -1);
-  x = fire("fire7", x, 48, 192, 192, false, -1);
-  x = fire("fire8", x, 64, 256, 256, false, -1);
-  x = fire("fire9", x, 64, 256, 256, false, -1);                                            // :309
-  x = fire("fire10", x, 64, 128, 128, true, fire5);                                         // :312-313
+  x = fire("fire7", x, 48, 192, 192, false, -1, 0, true);
+  x = fire("fire8", x, 64, 256, 256, false, -1, 0, true);
+  x = fire("fire9", x, 64, 256, 256, false, -1, 0, true);                                   // :309
+  x = fire("fire10", x, 64, 128, 128, true, fire5, 0, true);                                // :312-313
   x = fire("fire11", x, 32, 64, 64, true, cam3);                                            // :314-315
   x = fire("fire12", x, 16, 32, 32, true, cam1);                                            // :316-317
   x = fire("fire13", x, 16, 32, 32, true, -1, (int64_t)H * W * 64);                         // :318-319
@@ -626,6 +665,7 @@ inline void assign_formats(Graph* g) {
     if (t == g->t_input || producer[t] < 0 || readers[t] != 1 || other[t] != 0) continue;
     const Op& prod = g->ops[producer[t]];
     const Op& rd = g->ops[reader_op[t]];
+    if (prod.fsq_fused) { g->tensors[t].fmt = FMT_S16; continue; }   // the fused squeeze writes split-f16 only
     const bool narrow = prod.nsub == 1 ? (prod.pkh == 1 && prod.pkw == 1) : (prod.ow_mul == 2);  // 1x1 conv or up-conv
     if (!narrow || g->tensors[t].C % 8 != 0) continue;
     if (op_is_flat(rd) && rd.nsub == 1) continue;   // LDS-free 1x1 readers split in registers anyway
@@ -703,6 +743,17 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
       continue;
     }
     op_geometry(&op);
+    if (op.fsq_fused) {
+      if (!op.pair || op.nsub != 2 || op.sub[0].nctp != op.sub[1].nctp || op.sub[0].nctp != op.ntw * op.wn) {
+        g->error = "internal: fused squeeze on an op that cannot run as one merged block (" + op.name() + ")";
+        return PCLSEG_ERR_BAD_ARG;
+      }
+      op.fsq.nctp = (op.fsq.cout + 15) / 16;
+      op.fsq.w16_off = g->packed16_halfs;
+      g->packed16_halfs += fsq_w16_halfs(op);
+      op.fsq.b_off = g->packed_bias_floats;
+      g->packed_bias_floats += (int64_t)op.fsq.nctp * 16;
+    }
     for (int i = 0; i < op.nsub; ++i) {
       SubOp& su = op.sub[i];
       su.w32_off = g->packed32_floats;

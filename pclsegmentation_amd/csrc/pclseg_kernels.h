@@ -78,6 +78,10 @@ struct ConvArgs {
   int out_s16;  // write the output in split-f16 pair format
   unsigned* range_flag;  // sticky: set when a value that is split to f16 hi/lo has |v| >= 65504
   int wt;                // write-through output stores (see store_quad)
+  // fused squeeze of the NEXT FIRE module (conv_kernel FSQ): packed fragments, bias, couts, cout groups
+  const _Float16* fsq_w16;
+  const float* fsq_bias;
+  int fsq_q, fsq_ncg;
   int flip_bit;          // merged pairs: blocks with this bit of blockIdx.x set run the 1x1 half first (-1: none)
   int skw_lds_off;       // byte offset of the fused skip branch's [9][out_C] weights in dynamic LDS
   ConvSub sub[2];
@@ -162,7 +166,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // register tiles, two waves per SIMD that alternate between LDS reads and MFMA bursts): with
 // NW = 8 a block covers (8/WN)*MTW pixel segments x WN*NTW cout tiles per sub-conv, so the deep
 // FIRE layers stage each patch once for 128-256 output channels instead of once per 64.
-template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4>
+// FSQ = NQ > 0 (merged pair, 8 waves): the block does NOT write the pair's output.  It applies the NEXT
+// FIRE module's squeeze (1x1 conv C -> 16*NQ + BN + ReLU, nets/SqueezeSegV2.py:96-104,123-124) to its
+// tile and writes only that (split-f16): the 12-17 MB/scan tensors between fire4..fire10 are never
+// materialised.  The block holds all C channels of its pixels, split over the waves' cout groups:
+//   - a wave's bias+ReLU'd accumulators ARE an MFMA B operand as they stand — lane (p, g) holds
+//     channels {4g..4g+3} of tile 2t and of tile 2t+1, eight k-values of a 32-deep step — once the
+//     squeeze weights are packed in that channel order (host: pack_fsq); no data movement;
+//   - each wave accumulates the partial squeeze over ITS channels (both halves), the partials of the
+//     WN waves that share a pixel group are summed through LDS in a fixed order (deterministic), then
+//     bias + ReLU + split + store.
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int kThreads = NW * 64;
@@ -632,9 +646,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       // idle) and a store burst (matrix cores idle).  Half of the blocks therefore take the halves in
       // the opposite order, so one half's stores coincide with the other half's K loop.
       const int flip = a.flip_bit >= 0 ? (int)((blockIdx.x >> a.flip_bit) & 1u) : 0;
+      f32x4 acc2[FSQ > 0 ? MTW : 1][FSQ > 0 ? FSQ : 1];
+      if constexpr (FSQ > 0) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int qt = 0; qt < FSQ; ++qt) acc2[m][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma nounroll
       for (int half = 0; half < 2; ++half) {
-        const ConvSub& K = a.sub[(1 - half) ^ flip];
+        const int sidx = (1 - half) ^ flip;
+        const ConvSub& K = a.sub[sidx];
         if (half) {
 #pragma unroll
           for (int m = 0; m < MTW; ++m)
@@ -642,7 +664,83 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
             for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         kloop(K, 0, cin8);
-        epilogue(K, acc);
+        if constexpr (FSQ == 0) {
+          epilogue(K, acc);
+        } else {
+          // this half's channels -> partial squeeze sums.  K-step st of the partial GEMM covers the
+          // wave's cout tiles 2st and 2st+1: lane (p, g) contributes k = (g, j): j < 4 -> channel
+          // 4g+j of tile 2st, j >= 4 -> channel 4g+j-4 of tile 2st+1 (zero if NTW is odd and it is missing)
+          constexpr int NS = (NTW + 1) / 2;
+          f32x4 bv[NTW];
+#pragma unroll
+          for (int nn = 0; nn < NTW; ++nn)
+            bv[nn] = *reinterpret_cast<const f32x4*>(K.bias + (ct0 + nn) * 16 + g * 4);
+          const int cg = ct0 / NTW;   // this wave's cout group within the half
+#pragma unroll
+          for (int st = 0; st < NS; ++st) {
+            const _Float16* ap = a.fsq_w16 + ((((size_t)sidx * a.fsq_ncg + cg) * NS + st) * FSQ) * 1024 + lane * 8;
+            f16x8 ah[FSQ], al[FSQ];
+#pragma unroll
+            for (int qt = 0; qt < FSQ; ++qt) {
+              ah[qt] = *reinterpret_cast<const f16x8*>(ap + qt * 1024);
+              al[qt] = *reinterpret_cast<const f16x8*>(ap + qt * 1024 + 512);
+            }
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+              const f32x4 v0 = act4(acc[m][2 * st] + bv[2 * st], K.act);
+              const int n1 = 2 * st + 1 < NTW ? 2 * st + 1 : 2 * st;   // (resolved by the unroller)
+              f32x4 v1 = act4(acc[m][n1] + bv[n1], K.act);
+              if (2 * st + 1 >= NTW) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+              vmax = absmax4(absmax4(vmax, v0), v1);
+              f16x4 h0v, l0v, h1v, l1v;
+              split4(v0, h0v, l0v);
+              split4(v1, h1v, l1v);
+              const f16x8 bh = (f16x8){h0v[0], h0v[1], h0v[2], h0v[3], h1v[0], h1v[1], h1v[2], h1v[3]};
+              const f16x8 bl = (f16x8){l0v[0], l0v[1], l0v[2], l0v[3], l1v[0], l1v[1], l1v[2], l1v[3]};
+#pragma unroll
+              for (int qt = 0; qt < FSQ; ++qt) {
+                acc2[m][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[qt], bh, acc2[m][qt], 0, 0, 0);
+                acc2[m][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qt], bl, acc2[m][qt], 0, 0, 0);
+                acc2[m][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[qt], bh, acc2[m][qt], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      if constexpr (FSQ > 0) {
+        // partial sums -> LDS slab [wave][MTW*16 px][Q] (the patch is dead once every wave is here),
+        // then a fixed-order sum over the WN waves of each pixel group, squeeze bias + ReLU, split, store
+        constexpr int Q = FSQ * 16, PXW = MTW * 16;
+        float* slab = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int qt = 0; qt < FSQ; ++qt)
+            *reinterpret_cast<f32x4*>(slab + ((size_t)(wave * PXW + m * 16 + p) * Q + qt * 16 + 4 * g)) = acc2[m][qt];
+        __syncthreads();
+        constexpr int WMc = NW / WN, QQ = Q / 4;
+        for (int idx = tid; idx < WMc * PXW * QQ; idx += kThreads) {
+          const int px = idx / QQ, qq = idx - px * QQ;
+          const int wmi = px / PXW, pl = px - wmi * PXW;
+          f32x4 sum = *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4);
+#pragma unroll
+          for (int w = 0; w < WN; ++w)
+            sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * Q + qq * 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.0f);
+          const int seg = wmi * MTW + (pl >> 4), pp = pl & 15;
+          const int sr = seg / a.SEGW;
+          const int oh = h0 + sr, j = w0 + (seg - sr * a.SEGW) * 16 + pp;
+          if (oh < a.H && j < a.Wconv) {
+            f16x4 hi, lo;
+            split4(sum, hi, lo);
+            vmax = absmax4(vmax, sum);
+            _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + (((size_t)n * a.H + oh) * a.Wout + j) * (size_t)(2 * Q) + qq * 4;
+            *reinterpret_cast<f16x4*>(o16) = hi;
+            *reinterpret_cast<f16x4*>(o16 + Q) = lo;
+          }
+        }
       }
     } else {
       int chunk = 0;

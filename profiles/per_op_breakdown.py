@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Per-operator breakdown of a rocprofv3 --kernel-trace CSV of `bench.py` (SqueezeSegV2 workload).
 
-usage: per_op_breakdown.py <kernel_trace.csv>
+usage: per_op_breakdown.py <kernel_trace.csv> [launches per micro-batch]
 The engine launches a fixed kernel sequence per micro-batch; launches are folded modulo that
-sequence and the median duration of each position is printed."""
+sequence (its length is detected from the repeating kernel names) and the median duration of
+each position is printed."""
 import collections
 import csv
 import statistics
@@ -13,18 +14,33 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "pclseg" in r["Kernel_Na
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
 
-def fire(p, up=False):
-  return [p + "/squeeze"] + ([p + "/upconv"] if up else []) + [p + "/expand"]
+def fire(p, up=False, sq=True, fused=None):
+  return ([p + "/squeeze"] if sq else []) + ([p + "/upconv"] if up else []) + \
+         [p + "/expand" + ("+" + fused if fused else "")]
 
 
-ops = ["normalize", "conv1", "cam1", "pool1"] + fire("fire2") + ["cam2"] + fire("fire3") + ["cam3", "pool3"]
-ops += fire("fire4") + fire("fire5") + ["pool5"]
-for f in ("fire6", "fire7", "fire8", "fire9"):
-  ops += fire(f)
-for f in ("fire10", "fire11", "fire12", "fire13"):
-  ops += fire(f, True)
-ops += ["conv14+head"]
-per = int(sys.argv[2]) if len(sys.argv) > 2 else len(ops)
+def sequence(fused):
+  ops = ["normalize", "conv1", "cam1", "pool1"] + fire("fire2") + ["cam2"] + fire("fire3") + ["cam3", "pool3"]
+  if fused:   # fireN's expand blocks also compute fireN+1's squeeze (N = 4, 6, 7, 8, 9)
+    ops += fire("fire4", fused="sq5") + fire("fire5", sq=False) + ["pool5"]
+    ops += fire("fire6", fused="sq7") + fire("fire7", sq=False, fused="sq8") + fire("fire8", sq=False, fused="sq9")
+    ops += fire("fire9", sq=False, fused="sq10") + fire("fire10", True, sq=False)
+  else:
+    ops += fire("fire4") + fire("fire5") + ["pool5"]
+    for f in ("fire6", "fire7", "fire8", "fire9"):
+      ops += fire(f)
+    ops += fire("fire10", True)
+  for f in ("fire11", "fire12", "fire13"):
+    ops += fire(f, True)
+  return ops + ["conv14+head"]
+
+
+names = [r["Kernel_Name"] for r in rows]
+if len(sys.argv) > 2:
+  per = int(sys.argv[2])
+else:   # smallest period of the kernel-name sequence
+  per = next((p for p in range(8, 80) if len(names) >= 3 * p and names[:2 * p] == names[p:3 * p]), 37)
+ops = {37: sequence(False), 32: sequence(True)}.get(per, [])
 agg = collections.defaultdict(list)
 for i, r in enumerate(rows):
   agg[i % per].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -32,9 +48,9 @@ tot = 0
 for i in range(per):
   m = statistics.median(agg[i])
   tot += m
-  nm = ops[i] if i < len(ops) else "?"
+  nm = ops[i] if i < len(ops) else "op%d" % i
   r = rows[i]
-  print("%2d %-16s %8.1f us  grid=%dx%s lds=%s vgpr=%s+%s %s" % (
+  print("%2d %-18s %8.1f us  grid=%dx%s lds=%s vgpr=%s+%s %s" % (
     i, nm, m / 1e3, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"],
     r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["Kernel_Name"][8:44]))
 span = int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])

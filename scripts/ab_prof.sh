@@ -13,12 +13,22 @@ done
 python3 - "$@" <<'PY'
 import sys
 cfgs = sys.argv[1:]
-cols = [open("gpurun_out/ab_%d.txt" % (i + 1)).read().splitlines() for i in range(len(cfgs))]
+cols = []
+for i in range(len(cfgs)):
+  d, order = {}, []
+  for line in open("gpurun_out/ab_%d.txt" % (i + 1)).read().splitlines():
+    parts = line.split()
+    if len(parts) > 3 and parts[3] == "us":
+      d[parts[1]] = parts[2]; order.append(parts[1])
+    elif line.startswith("sum"):
+      d["__sum__"] = line[:60]
+  cols.append((d, order))
 print("configs:", cfgs)
-for k in range(len(cols[0])):
-  parts = cols[0][k].split()
-  if len(parts) > 3 and parts[3] == "us":
-    print("%-18s" % parts[1], "  ".join("%8s" % c[k].split()[2] for c in cols))
-  else:
-    for c in cols: print(c[k][:60])
+names = []
+for d, order in cols:
+  for n in order:
+    if n not in names: names.append(n)
+for n in names:
+  print("%-20s" % n, "  ".join("%8s" % d.get(n, "-") for d, _ in cols))
+for d, _ in cols: print(d.get("__sum__", ""))
 PY
