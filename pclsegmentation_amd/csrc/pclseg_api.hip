@@ -276,13 +276,15 @@ inline bool pair_cfg_ok(const Op& op) {
 #undef PCLSEG_X
   return false;
 }
-// merged pair + fused next squeeze: (mtw, ntw, wn, nq) of fire8/9 (256+256 -> 64), fire6 (192+192 -> 48),
-// fire7 (192+192 -> 64), fire4 (128+128 -> 32); 8 waves, 64-pixel tiles
-#define PCLSEG_FSQ_CFGS(X) X(4, 2, 8, 4) X(2, 3, 4, 3) X(2, 3, 4, 4) X(4, 1, 8, 2)
-hipError_t launch_conv_fsq(const Op& op, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
-#define PCLSEG_X(M_, N_, W_, Q_) \
-  if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16) { \
-    auto kfn = conv_kernel<M_, N_, W_, false, true, 0, true, 8, Q_>; \
+// merged pair + fused next squeeze, 8 waves: (mtw, ntw, wn, nq, epi) of fire8/9 (256+256 -> 64), fire6
+// (192+192 -> 48), fire7 (192+192 -> 64), fire4 (128+128 -> 32) on 64-pixel tiles, and the FIREUP pairs
+// with their skip add: fire10 (128+128 -> 32, 64 px), fire11 (64+64 -> 16, 128 px), fire12 (32+32 -> 16, 256 px)
+#define PCLSEG_FSQ_CFGS(X) X(4, 2, 8, 4, 0) X(2, 3, 4, 3, 0) X(2, 3, 4, 4, 0) X(4, 1, 8, 2, 0) \
+                           X(4, 1, 8, 2, 1) X(4, 1, 4, 1, 1) X(4, 1, 2, 1, 1)
+hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+#define PCLSEG_X(M_, N_, W_, Q_, E_) \
+  if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16 && epi == E_) { \
+    auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_>; \
     if (lds > 64 * 1024) { \
       static bool raised = false;   /* once per kernel: dynamic LDS beyond the 64 KiB default */ \
       if (!raised) { \
@@ -436,7 +438,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     a.fsq_q = op.fsq.nctp * 16;
     a.fsq_ncg = op.sub[0].nctp / op.ntw;
     a.flip_bit = -1;
-    return launch_conv_fsq(op, grid, lds, s, a);
+    return launch_conv_fsq(op, epi, grid, lds, s, a);
   }
   if (pair) {
     static const int wt = getenv("PCLSEG_WT") ? atoi(getenv("PCLSEG_WT")) : 1;

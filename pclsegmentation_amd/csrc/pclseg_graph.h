@@ -187,9 +187,11 @@ inline void op_geometry(Op* op) {
   static const int geom_only = getenv("PCLSEG_FSQ_GEOM_ONLY") ? atoi(getenv("PCLSEG_FSQ_GEOM_ONLY")) : 0;   // debug
   if (op->fsq_fused || (geom_only && op->pair && (nct == 16 || nct == 12 || nct == 8) && op->res1 < 0)) {   // 8 waves on a 64-pixel tile, all couts of both halves in the block
     op->nw = 8;
-    if (nct == 16) { op->wn = 8; op->ntw = 2; op->mtw = 4; }
-    else if (nct == 12) { op->wn = 4; op->ntw = 3; op->mtw = 2; }
-    else { op->wn = 8; op->ntw = 1; op->mtw = 4; }
+    if (nct == 16) { op->wn = 8; op->ntw = 2; op->mtw = 4; }        // 64 px x (256 + 256) couts
+    else if (nct == 12) { op->wn = 4; op->ntw = 3; op->mtw = 2; }   // 64 px x (192 + 192)
+    else if (nct == 8) { op->wn = 8; op->ntw = 1; op->mtw = 4; }    // 64 px x (128 + 128)
+    else if (nct == 4) { op->wn = 4; op->ntw = 1; op->mtw = 4; }    // 128 px x (64 + 64)
+    else { op->wn = 2; op->ntw = 1; op->mtw = 4; }                  // 256 px x (32 + 32)
   }
   if (!op->fsq_fused) if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw[,nw];subname=..."
     const std::string key = op->sub[0].name + "=";
@@ -458,7 +460,8 @@ inline void build_squeezesegv2(Graph* g) {
     return out;
   };
   int last_expand = -1;
-  // fireN's expand output feeds ONLY fireN+1's squeeze for N = 4, 6, 7, 8, 9 (:302-312): there the
+  // fireN's output (for the FIREUP modules: after its skip add) feeds ONLY fireN+1's squeeze for
+  // N = 4, 6, 7, 8, 9 (:302-312) and N = 10, 11, 12 (:313-318): there the
   // squeeze is computed by fireN's expand blocks and the expand output is never written (split-f16
   // arithmetic only; every intermediate stays observable with KEEP_ACTIVATIONS, which disables it)
   static const int fuse_env = getenv("PCLSEG_FUSE_SQ") ? atoi(getenv("PCLSEG_FUSE_SQ")) : 1;
@@ -469,7 +472,8 @@ inline void build_squeezesegv2(Graph* g) {
                   int64_t skip_floats = 0, bool fuse_prev = false) {
     int s;
     static const int fuse_mask = getenv("PCLSEG_FUSE_MASK") ? atoi(getenv("PCLSEG_FUSE_MASK")) : 255;   // debug: bit per fusion
-    const int fuse_bit = p == "fire5" ? 1 : p == "fire7" ? 2 : p == "fire8" ? 4 : p == "fire9" ? 8 : 16;
+    const int fuse_bit = p == "fire5" ? 1 : p == "fire7" ? 2 : p == "fire8" ? 4 : p == "fire9" ? 8 : p == "fire10" ? 16 :
+                         p == "fire11" ? 32 : p == "fire12" ? 64 : 128;
     if (fuse_prev && fuse && (fuse_mask & fuse_bit) && last_expand >= 0 && g->ops[last_expand].out == x) {
       const TensorInfo tx = g->tensors[x];
       Op& pe = g->ops[last_expand];
@@ -518,9 +522,9 @@ inline void build_squeezesegv2(Graph* g) {
   x = fire("fire8", x, 64, 256, 256, false, -1, 0, true);
   x = fire("fire9", x, 64, 256, 256, false, -1, 0, true);                                   // :309
   x = fire("fire10", x, 64, 128, 128, true, fire5, 0, true);                                // :312-313
-  x = fire("fire11", x, 32, 64, 64, true, cam3);                                            // :314-315
-  x = fire("fire12", x, 16, 32, 32, true, cam1);                                            // :316-317
-  x = fire("fire13", x, 16, 32, 32, true, -1, (int64_t)H * W * 64);                         // :318-319
+  x = fire("fire11", x, 32, 64, 64, true, cam3, 0, true);                                   // :314-315
+  x = fire("fire12", x, 16, 32, 32, true, cam1, 0, true);                                   // :316-317
+  x = fire("fire13", x, 16, 32, 32, true, -1, (int64_t)H * W * 64, true);                   // :318-319
   g->ops[last_expand].sk_in = x_in;
   g->ops[last_expand].sk = skip_sub;
   b.touch(x_in, last_expand);

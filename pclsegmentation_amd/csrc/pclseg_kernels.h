@@ -685,11 +685,32 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
               ah[qt] = *reinterpret_cast<const f16x8*>(ap + qt * 1024);
               al[qt] = *reinterpret_cast<const f16x8*>(ap + qt * 1024 + 512);
             }
+            // FIREUP pairs add a skip tensor to the pair output before the next squeeze reads it
+            // (nets/SqueezeSegV2.py:313-317): fetch this step's residual quads up front
+            constexpr bool kRes = EPI == 1;
+            f32x4 rq[kRes ? MTW : 1][2];
+            if constexpr (kRes) {
+#pragma unroll
+              for (int m = 0; m < MTW; ++m) {
+                const int oh = h0 + seg_r[m];
+                const int j = w0 + seg_q[m] * 16 + p;
+                const bool valid = a.res1 && (oh < a.H) && (j < a.Wconv);
+                const float* rp = a.res1 + (((size_t)n * a.H + oh) * a.Wout + j) * a.res1_C + K.co_off + g * 4;
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                  const int nn = 2 * st + t2 < NTW ? 2 * st + t2 : 2 * st;
+                  const bool ok = valid && (2 * st + t2 < NTW) && ((ct0 + nn) * 16 + g * 4 < K.Cout);
+                  const f32x4 t = *reinterpret_cast<const f32x4*>(ok ? rp + (ct0 + nn) * 16 : a.res1 ? a.res1 : a.in);
+                  rq[m][t2] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+              }
+            }
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-              const f32x4 v0 = act4(acc[m][2 * st] + bv[2 * st], K.act);
+              f32x4 v0 = act4(acc[m][2 * st] + bv[2 * st], K.act);
               const int n1 = 2 * st + 1 < NTW ? 2 * st + 1 : 2 * st;   // (resolved by the unroller)
               f32x4 v1 = act4(acc[m][n1] + bv[n1], K.act);
+              if constexpr (kRes) { v0 += rq[m][0]; v1 += rq[m][1]; }
               if (2 * st + 1 >= NTW) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
               vmax = absmax4(absmax4(vmax, v0), v1);
               f16x4 h0v, l0v, h1v, l1v;

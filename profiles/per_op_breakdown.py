@@ -20,18 +20,26 @@ def fire(p, up=False, sq=True, fused=None):
 
 
 def sequence(fused):
+  """fused 0: every squeeze its own launch; 1: fireN's expand blocks also compute fireN+1's squeeze for
+  N = 4, 6, 7, 8, 9; 2: also for the FIREUP chain N = 10, 11, 12."""
   ops = ["normalize", "conv1", "cam1", "pool1"] + fire("fire2") + ["cam2"] + fire("fire3") + ["cam3", "pool3"]
-  if fused:   # fireN's expand blocks also compute fireN+1's squeeze (N = 4, 6, 7, 8, 9)
+  if fused:
     ops += fire("fire4", fused="sq5") + fire("fire5", sq=False) + ["pool5"]
     ops += fire("fire6", fused="sq7") + fire("fire7", sq=False, fused="sq8") + fire("fire8", sq=False, fused="sq9")
-    ops += fire("fire9", sq=False, fused="sq10") + fire("fire10", True, sq=False)
+    ops += fire("fire9", sq=False, fused="sq10")
+    if fused == 2:
+      ops += fire("fire10", True, sq=False, fused="sq11") + fire("fire11", True, sq=False, fused="sq12")
+      ops += fire("fire12", True, sq=False, fused="sq13") + fire("fire13", True, sq=False)
+    else:
+      ops += fire("fire10", True, sq=False)
   else:
     ops += fire("fire4") + fire("fire5") + ["pool5"]
     for f in ("fire6", "fire7", "fire8", "fire9"):
       ops += fire(f)
     ops += fire("fire10", True)
-  for f in ("fire11", "fire12", "fire13"):
-    ops += fire(f, True)
+  if fused != 2:
+    for f in ("fire11", "fire12", "fire13"):
+      ops += fire(f, True)
   return ops + ["conv14+head"]
 
 
@@ -40,7 +48,7 @@ if len(sys.argv) > 2:
   per = int(sys.argv[2])
 else:   # smallest period of the kernel-name sequence
   per = next((p for p in range(8, 80) if len(names) >= 3 * p and names[:2 * p] == names[p:3 * p]), 37)
-ops = {37: sequence(False), 32: sequence(True)}.get(per, [])
+ops = {37: sequence(0), 32: sequence(1), 29: sequence(2)}.get(per, [])
 agg = collections.defaultdict(list)
 for i, r in enumerate(rows):
   agg[i % per].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

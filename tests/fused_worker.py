@@ -29,7 +29,8 @@ O.forward("squeezesegv2", model.weights, lidar, mask, mc.CLASSES.index("None"), 
 names = [t[0] for t in eng.tensors()]
 W = O._W(model.weights, np.float64)
 bad = 0
-for src, dst in (("fire4", "fire5"), ("fire6", "fire7"), ("fire7", "fire8"), ("fire8", "fire9"), ("fire9", "fire10")):
+for src, dst in (("fire4", "fire5"), ("fire6", "fire7"), ("fire7", "fire8"), ("fire8", "fire9"), ("fire9", "fire10"),
+                 ("fire10", "fire11"), ("fire11", "fire12"), ("fire12", "fire13")):
   if src in names and eng.tensors()[names.index(src)][1][0] > 0:
     pass   # (the pair output tensor still exists in the plan but is never written when fused)
   want = O.relu(W.bn(W.conv(taps[src], dst + "/squeeze"), dst + "/squeeze_bn"))
