@@ -235,6 +235,7 @@ hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const 
     switch (epi) {
       case 0: PCLSEG_GO(0); break;
       case 1: PCLSEG_GO(1); break;
+      case 3: if constexpr (NW == 8 && NTW == 1) { PCLSEG_GO(3); break; } else return hipErrorInvalidValue;
       default: return hipErrorInvalidValue;
     }
   } else {
@@ -267,7 +268,7 @@ hipError_t launch_conv_cfg(int mtw, int ntw, int wn, int epi, dim3 grid, size_t 
 
 // merged FIRE expand pair (split-f16 mode): the block shapes the reference's FIRE sizes use
 // (pclseg_graph.h: pair_geometry); (mtw, ntw, wn, nw)
-#define PCLSEG_PAIR_CFGS(X) X(4, 2, 2, 4) X(4, 2, 1, 4) X(8, 2, 8, 8) X(4, 3, 4, 8) X(4, 2, 4, 8) X(4, 2, 2, 8) X(4, 2, 8, 8) X(2, 3, 4, 8) X(4, 1, 8, 8)
+#define PCLSEG_PAIR_CFGS(X) X(4, 2, 2, 4) X(4, 2, 1, 4) X(8, 2, 8, 8) X(4, 3, 4, 8) X(4, 2, 4, 8) X(4, 2, 2, 8) X(4, 2, 8, 8) X(2, 3, 4, 8) X(4, 1, 8, 8) X(4, 1, 2, 8)
 inline bool pair_cfg_ok(const Op& op) {
   if (op.sub[0].nctp != op.sub[1].nctp || op.ck16 < op.cin_t) return false;
   if (op.fsq_fused) return true;   // its shapes are PCLSEG_FSQ_CFGS (launch_conv_fsq)
@@ -319,7 +320,11 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     // exact-f32 sweep of a graph planned for split-f16 (PCLSEG_FLAG_RANGE_FALLBACK): the 8-wave
     // block shapes exist only for the split-f16 kernels; any 4-wave shape whose cout group divides
     // the packed tile count reads the same fragments
-    op.nw = 4; op.mtw = 4; op.ntw = 2; op.wn = 2;
+    const int tiles = op.sub[0].nctp;   // (both halves of a pair carry the same count)
+    op.nw = 4; op.mtw = 4;
+    if (tiles % 4 == 0) { op.ntw = 2; op.wn = 2; }
+    else if (tiles % 2 == 0) { op.ntw = 2; op.wn = 1; }
+    else { op.ntw = 1; op.wn = 1; }
     op.ck32 = 32;
     while (op.ck32 > 16 && lds_bytes_f32(op, op.ck32) > 64 * 1024) op.ck32 /= 2;
   }
@@ -413,7 +418,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     if (lds > 160 * 1024) return hipErrorInvalidValue;
   } else if (lds > 64 * 1024) return hipErrorInvalidValue;
   // (the fused-skip-branch epilogue of fire13 needs more registers than the merged kernel has left)
-  const bool pair = !exact && op.pair && pair_cfg_ok(op) && !a.skx && !a.res2;
+  const bool pair = !exact && op.pair && pair_cfg_ok(op) && (!a.skx || (op.nw == 8 && op.ntw == 1 && !a.res1)) && !a.res2;
   if (pair) {  // one block = cout group of the 3x3 half + the same group of the 1x1 half
     ny = a.sub[1].ny;
     a.ny = ny;

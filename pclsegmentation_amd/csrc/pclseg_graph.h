@@ -163,6 +163,8 @@ inline void pair_geometry(Op* op) {
   // measured per layer (one-lane us, 4-wave vs 8-wave blocks): fire4/5 27.4/31.0 vs 29.7/31.5,
   // fire6/7 28.1/28.2 vs 30.3/29.0, fire8/9 42.5/43.1 vs 41.7/41.9, fire10 53.5 vs 46.3: big tiles pay
   // from 256 couts per half, and for the 128-cout FIREUP pair (fire10)
+  if (op->sk_in >= 0 && nct == 2) { op->nw = 8; op->wn = 2; op->ntw = 1; op->mtw = 4; return; }   // fire13: 256 px x (32 + 32),
+                                                   // the fused skip-branch epilogue needs the 8-wave register budget
   if (nct == 16) { op->nw = 8; op->wn = 8; op->ntw = 2; op->mtw = 8; }                        // 128 px x 256 couts
   else if (nct == 8 && (op->res1 >= 0 || big == 2)) { op->nw = 8; op->wn = 4; op->ntw = 2; op->mtw = 4; }  // 128 px x 128 couts
   else if (nct == 12 && big == 2) { op->nw = 8; op->wn = 4; op->ntw = 3; op->mtw = 4; }       // 128 px x 192 couts

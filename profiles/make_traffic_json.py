@@ -2,7 +2,9 @@
 """HBM-side traffic per scan from two rocprofv3 PMC passes of `bench.py` (FETCH_SIZE, WRITE_SIZE in
 separate runs, kernel-trace only), summed over the engine's kernels.
 
-usage: make_traffic_json.py <fetch_dir> <write_dir> <scans_profiled> <alg_bytes_per_scan> > rNN_traffic.json
+usage: make_traffic_json.py <fetch_dir> <write_dir> <scans_profiled> > rNN_traffic.json
+The file records the sha of the kernel sources it was measured on (bench.csrc_sha); bench.py only
+quotes the figure while that sha matches the build it is running.
 FETCH_SIZE is doubled (gfx950 counts a 128-byte request as 64 B, MI355X_MICROARCH.md HBM section)."""
 import csv
 import glob
@@ -18,13 +20,16 @@ def total(d, counter):
 
 
 fetch_kb, write_kb = total(sys.argv[1], "FETCH_SIZE"), total(sys.argv[2], "WRITE_SIZE")
-scans, alg = int(sys.argv[3]), int(sys.argv[4])
+scans = int(sys.argv[3])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (csrc_sha only)
 print(json.dumps({
-  "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0",
+  "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-secondary",
   "scans_profiled": scans,
   "FETCH_SIZE_KB_total": fetch_kb,
   "WRITE_SIZE_KB_total": write_kb,
   "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
   "hbm_bytes_per_scan": (2 * fetch_kb + write_kb) * 1024 / scans,
-  "alg_bytes_per_scan": alg,
+  "alg_bytes_per_scan": 728367104,
+  "csrc_sha": bench.csrc_sha(),
 }, indent=1))
