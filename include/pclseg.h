@@ -14,7 +14,8 @@
  *     last failure is available from pclseg_last_error().
  *   - The caller owns every buffer it passes.  `mem` says where the caller's buffers live:
  *     PCLSEG_MEM_HOST (the library copies over PCIe itself) or PCLSEG_MEM_DEVICE (pointers
- *     are HIP device pointers on the handle's device; nothing is copied).
+ *     are HIP device pointers on the handle's device; nothing is copied) or
+ *     PCLSEG_MEM_HOST_ASYNC (page-locked host buffers, asynchronous).
  *   - One handle = one device + one stream; a handle is not thread-safe, independent
  *     handles are.  Forward calls are asynchronous on the handle's stream in
  *     PCLSEG_MEM_DEVICE mode (call pclseg_sync or synchronise the stream) and synchronous on
@@ -55,7 +56,13 @@ typedef enum pclseg_arch {
   PCLSEG_ARCH_DARKNET53 = 2
 } pclseg_arch;
 
-typedef enum pclseg_mem { PCLSEG_MEM_HOST = 0, PCLSEG_MEM_DEVICE = 1 } pclseg_mem;
+typedef enum pclseg_mem {
+  PCLSEG_MEM_HOST = 0,       /* host buffers (pinned or pageable); the call returns when the outputs are there */
+  PCLSEG_MEM_DEVICE = 1,     /* device buffers; asynchronous on the handle's stream */
+  PCLSEG_MEM_HOST_ASYNC = 2  /* PAGE-LOCKED host buffers; the call only enqueues (uploads, kernels, downloads),
+                                pclseg_sync waits: consecutive calls overlap, the GPU never idles while the
+                                CPU enqueues the next batch */
+} pclseg_mem;
 
 /* desc.flags */
 #define PCLSEG_FLAG_KEEP_ACTIVATIONS 1u /* debug: no workspace aliasing, so every

@@ -64,8 +64,13 @@ struct pclseg_handle {
     float* d_logits = nullptr; size_t logits_bytes = 0;
     void* p_in = nullptr; size_t p_in_bytes = 0;
     void* p_mask = nullptr; size_t p_mask_bytes = 0;
-    hipEvent_t ev_bounce = nullptr; bool bounce_busy = false;
-  } hl[kMaxLanes];
+    // ev_in: the slot's H2D copies landed; ev_done: its kernels finished; ev_out: its D2H copies finished
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+    bool used = false;
+  } hl[2 * kMaxLanes];            // two slots per lane: micro-batch k+1 of a lane uploads while k computes
+  bool host_async_pending = false;   // PCLSEG_MEM_HOST_ASYNC calls enqueued since the last pclseg_sync
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // dedicated copy streams (SDMA engines run beside the kernels)
+  hipEvent_t ev_copy_tail = nullptr;
   int32_t* p_preds = nullptr; size_t p_preds_bytes = 0;
   float* p_probs = nullptr; size_t p_probs_bytes = 0;
   float* p_logits = nullptr; size_t p_logits_bytes = 0;
@@ -80,6 +85,7 @@ struct pclseg_handle {
     bool valid = false;
     const float* input = nullptr; bool raw = false; const uint8_t* mask_in = nullptr; int n = 0;
     int32_t* preds = nullptr; float* probs = nullptr; float* logits = nullptr; uint8_t* mask_out = nullptr;
+    int mem = PCLSEG_MEM_DEVICE;
   } last;
   std::string err;
 };
@@ -580,8 +586,10 @@ int join_lanes(pclseg_handle* h) {
   return PCLSEG_OK;
 }
 void drain_after_error(pclseg_handle* h) {
+  if (h->s_h2d) (void)hipStreamSynchronize(h->s_h2d);
   for (int l = 0; l < h->nlanes; ++l)
     if (h->lane_stream[l]) (void)hipStreamSynchronize(h->lane_stream[l]);
+  if (h->s_d2h) (void)hipStreamSynchronize(h->s_d2h);
   (void)hipStreamSynchronize(h->stream);
   (void)hipGetLastError();
 }
@@ -621,7 +629,8 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
   const size_t HW = (size_t)g.desc.height * g.desc.width;
   const int NC = g.desc.num_class;
   const int cin = raw ? 5 : 6;
-  const bool host = mem == PCLSEG_MEM_HOST;
+  const bool host = mem == PCLSEG_MEM_HOST || mem == PCLSEG_MEM_HOST_ASYNC;
+  const bool host_async = mem == PCLSEG_MEM_HOST_ASYNC;
   const bool multi = h->nlanes > 1;
 
   // Micro-batches: at most g.micro_batch scans each, their number rounded up to a multiple of the
@@ -634,21 +643,36 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
 
   bool in_pinned = false, mask_pinned = false;
   int32_t* o_preds = preds; float* o_probs = probs; float* o_logits = logits; uint8_t* o_mask = mask_out;
+  const int nslots = std::min(2 * h->nlanes, nmb);
   if (host) {
     int rc;
-    for (int l = 0; l < std::min(h->nlanes, nmb); ++l)
-      if ((rc = ensure_host_lane(h, l, (size_t)mb_max * HW * cin * sizeof(float), (size_t)mb_max * HW, NC,
-                                 probs != nullptr, logits != nullptr))) return rc;
+    if (!h->s_h2d) {
+      HIP_TRY(h, hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
+      HIP_TRY(h, hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy_tail, hipEventDisableTiming));
+    }
     in_pinned = is_pinned_host(input);
     mask_pinned = raw || is_pinned_host(mask_in);
-    if (!in_pinned || !mask_pinned)
-      for (int l = 0; l < std::min(h->nlanes, nmb); ++l) {
-        pclseg_handle::HostLane& L = h->hl[l];
-        if (!in_pinned && (rc = ensure_pinned(h, (void**)&L.p_in, &L.p_in_bytes, (size_t)mb_max * HW * cin * sizeof(float)))) return rc;
-        if (!mask_pinned && (rc = ensure_pinned(h, (void**)&L.p_mask, &L.p_mask_bytes, (size_t)mb_max * HW))) return rc;
-        if (!L.ev_bounce) HIP_TRY(h, hipEventCreateWithFlags(&L.ev_bounce, hipEventDisableTiming));
-        L.bounce_busy = false;
+    for (int l = 0; l < nslots; ++l) {
+      pclseg_handle::HostLane& L = h->hl[l];
+      if ((rc = ensure_host_lane(h, l, (size_t)mb_max * HW * cin * sizeof(float), (size_t)mb_max * HW, NC,
+                                 probs != nullptr, logits != nullptr))) return rc;
+      if (!in_pinned && (rc = ensure_pinned(h, (void**)&L.p_in, &L.p_in_bytes, (size_t)mb_max * HW * cin * sizeof(float)))) return rc;
+      if (!mask_pinned && (rc = ensure_pinned(h, (void**)&L.p_mask, &L.p_mask_bytes, (size_t)mb_max * HW))) return rc;
+      if (!L.ev_in) {
+        HIP_TRY(h, hipEventCreateWithFlags(&L.ev_in, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&L.ev_out, hipEventDisableTiming));
       }
+      if (!host_async && !h->host_async_pending) L.used = false;   // nothing of an earlier call is in flight
+    }
+    if (host_async) {
+      if (!in_pinned || !mask_pinned || !is_pinned_host(preds) || (probs && !is_pinned_host(probs)) ||
+          (logits && !is_pinned_host(logits)) || (mask_out && !is_pinned_host(mask_out)))
+        return fail(h, PCLSEG_ERR_BAD_ARG, "PCLSEG_MEM_HOST_ASYNC needs page-locked host buffers "
+                                           "(pclseg_host_alloc / hipHostMalloc / hipHostRegister)");
+      h->host_async_pending = true;
+    }
     // pageable outputs: full-size pinned bounce, copied out after the fence
     if (!is_pinned_host(preds)) {
       if ((rc = ensure_pinned(h, (void**)&h->p_preds, &h->p_preds_bytes, (size_t)n * HW * sizeof(int32_t)))) return rc;
@@ -670,7 +694,8 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
 
   NormArgs na;
   for (int i = 0; i < 5; ++i) { na.mean[i] = g.desc.mean[i]; na.std[i] = g.desc.std[i]; }
-  if (multi) {  // lanes start after everything already queued on the caller's stream (inputs)
+  if (multi && !host) {  // lanes start after everything already queued on the caller's stream (device inputs);
+                         // host inputs depend on nothing there, and consecutive host-async calls must overlap
     HIP_TRY(h, hipEventRecord(h->ev_in, h->stream));
     for (int l = 0; l < h->nlanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->ev_in, 0));
   }
@@ -680,7 +705,7 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     const size_t P = (size_t)cnt * HW;
     const int lane = mbi % h->nlanes;
     const hipStream_t stream = multi ? h->lane_stream[lane] : h->stream;
-    pclseg_handle::HostLane& L = h->hl[lane];
+    pclseg_handle::HostLane& L = h->hl[host ? mbi % (2 * h->nlanes) : lane];   // slot s always serves lane s % nlanes
     float* d_lidar8 = h->d_arena_lane[lane] + g.tensors[g.t_input].offset;
     const float* d_in = input + (size_t)s0 * HW * cin;
     const uint8_t* d_mask_in = mask_in ? mask_in + (size_t)s0 * HW : nullptr;
@@ -689,23 +714,27 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     float* d_logits = logits ? logits + (size_t)s0 * HW * NC : nullptr;
     uint8_t* d_mask_out = mask_out ? mask_out + (size_t)s0 * HW : nullptr;
     if (host) {
+      // upload on the H2D stream into this micro-batch's slot (two slots per lane, so the upload of the
+      // lane's NEXT micro-batch runs while this one computes)
       const float* src = d_in;
       const uint8_t* msrc = d_mask_in;
+      if (L.used) HIP_TRY(h, hipStreamWaitEvent(h->s_h2d, L.ev_done, 0));   // slot's previous kernels have read it
       if (!in_pinned || !mask_pinned) {
-        // the bounce slab of this lane is free once the H2D copies of its previous micro-batch ran
-        if (L.bounce_busy) HIP_TRY(h, hipEventSynchronize(L.ev_bounce));
+        if (L.used) HIP_TRY(h, hipEventSynchronize(L.ev_in));   // the bounce slab's previous upload has left it
         if (!in_pinned) { memcpy(L.p_in, d_in, P * cin * sizeof(float)); src = (const float*)L.p_in; }
         if (!mask_pinned) { memcpy(L.p_mask, d_mask_in, P); msrc = (const uint8_t*)L.p_mask; }
       }
-      HIP_TRY(h, hipMemcpyAsync(L.d_in, src, P * cin * sizeof(float), hipMemcpyHostToDevice, stream));
-      if (!raw) HIP_TRY(h, hipMemcpyAsync(L.d_maskin, msrc, P, hipMemcpyHostToDevice, stream));
-      if (!in_pinned || !mask_pinned) { HIP_TRY(h, hipEventRecord(L.ev_bounce, stream)); L.bounce_busy = true; }
+      HIP_TRY(h, hipMemcpyAsync(L.d_in, src, P * cin * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
+      if (!raw) HIP_TRY(h, hipMemcpyAsync(L.d_maskin, msrc, P, hipMemcpyHostToDevice, h->s_h2d));
+      HIP_TRY(h, hipEventRecord(L.ev_in, h->s_h2d));
+      HIP_TRY(h, hipStreamWaitEvent(stream, L.ev_in, 0));
+      if (L.used) HIP_TRY(h, hipStreamWaitEvent(stream, L.ev_out, 0));      // slot's previous results have left
       d_in = (const float*)L.d_in;
       d_mask_in = L.d_maskin;
       d_preds = L.d_preds;
       d_probs = probs ? L.d_probs : nullptr;
       d_logits = logits ? L.d_logits : nullptr;
-      d_mask_out = nullptr;   // the lane's own mask slab, copied out below
+      d_mask_out = raw ? L.d_maskin : nullptr;   // raw mode: the slot's own mask slab (copied out below)
     }
     const uint8_t* mask_mb;
     if (raw) {
@@ -720,11 +749,15 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     }
     int rc = run_ops(h, lane, cnt, mask_mb, d_preds, d_probs, d_logits, exact);
     if (rc) return rc;
-    if (host) {
-      HIP_TRY(h, hipMemcpyAsync(o_preds + (size_t)s0 * HW, d_preds, P * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-      if (probs) HIP_TRY(h, hipMemcpyAsync(o_probs + (size_t)s0 * HW * NC, d_probs, P * NC * sizeof(float), hipMemcpyDeviceToHost, stream));
-      if (logits) HIP_TRY(h, hipMemcpyAsync(o_logits + (size_t)s0 * HW * NC, d_logits, P * NC * sizeof(float), hipMemcpyDeviceToHost, stream));
-      if (mask_out) HIP_TRY(h, hipMemcpyAsync(o_mask + (size_t)s0 * HW, mask_mb, P, hipMemcpyDeviceToHost, stream));
+    if (host) {   // results leave on the D2H stream once the slot's kernels are done
+      HIP_TRY(h, hipEventRecord(L.ev_done, stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->s_d2h, L.ev_done, 0));
+      HIP_TRY(h, hipMemcpyAsync(o_preds + (size_t)s0 * HW, d_preds, P * sizeof(int32_t), hipMemcpyDeviceToHost, h->s_d2h));
+      if (probs) HIP_TRY(h, hipMemcpyAsync(o_probs + (size_t)s0 * HW * NC, d_probs, P * NC * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+      if (logits) HIP_TRY(h, hipMemcpyAsync(o_logits + (size_t)s0 * HW * NC, d_logits, P * NC * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+      if (mask_out) HIP_TRY(h, hipMemcpyAsync(o_mask + (size_t)s0 * HW, mask_mb, P, hipMemcpyDeviceToHost, h->s_d2h));
+      HIP_TRY(h, hipEventRecord(L.ev_out, h->s_d2h));
+      L.used = true;
     }
     h->last_count = cnt;
     h->last_exact = exact;
@@ -734,7 +767,11 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
   int rc = join_lanes(h);  // the caller's stream continues only after every lane has drained
   if (rc) return rc;
   if (host) {
+    HIP_TRY(h, hipEventRecord(h->ev_copy_tail, h->s_d2h));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_copy_tail, 0));
+    if (host_async) return PCLSEG_OK;   // pclseg_sync waits (and reports the range guard)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->host_async_pending = false;
     if (o_preds != preds) memcpy(preds, o_preds, (size_t)n * HW * sizeof(int32_t));
     if (probs && o_probs != probs) memcpy(probs, o_probs, (size_t)n * HW * NC * sizeof(float));
     if (logits && o_logits != logits) memcpy(logits, o_logits, (size_t)n * HW * NC * sizeof(float));
@@ -766,14 +803,15 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
   if (!input || !preds) return fail(h, PCLSEG_ERR_BAD_ARG, "input and preds must not be NULL");
   if (!raw && !mask_in) return fail(h, PCLSEG_ERR_BAD_ARG, "mask must not be NULL");
   if (n <= 0) return fail(h, PCLSEG_ERR_BAD_ARG, fmt("n must be positive, got %d", n));
-  if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE)
+  if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE && mem != PCLSEG_MEM_HOST_ASYNC)
     return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
   DeviceGuard guard(h->device);
   int rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, h->exact);
   if (rc) { drain_after_error(h); return rc; }
   h->last.valid = false;
-  if (mem == PCLSEG_MEM_DEVICE) {   // asynchronous: pclseg_sync reports / repairs a range overflow
+  if (mem != PCLSEG_MEM_HOST) {   // asynchronous: pclseg_sync reports / repairs a range overflow
     h->last.valid = true;
+    h->last.mem = mem;
     h->last.input = input; h->last.raw = raw; h->last.mask_in = mask_in; h->last.n = n;
     h->last.preds = preds; h->last.probs = probs; h->last.logits = logits; h->last.mask_out = mask_out;
     return PCLSEG_OK;
@@ -940,14 +978,17 @@ int pclseg_destroy(pclseg_handle* h) {
     if (h->d_mask_lane[l]) (void)hipFree(h->d_mask_lane[l]);
   }
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-  for (int l = 0; l < pclseg_handle::kMaxLanes; ++l) {
+  for (int l = 0; l < 2 * pclseg_handle::kMaxLanes; ++l) {
     pclseg_handle::HostLane& L = h->hl[l];
     void* dev[] = {L.d_in, L.d_maskin, L.d_preds, L.d_probs, L.d_logits};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (L.p_in) (void)hipHostFree(L.p_in);
     if (L.p_mask) (void)hipHostFree(L.p_mask);
-    if (L.ev_bounce) (void)hipEventDestroy(L.ev_bounce);
+    for (hipEvent_t e : {L.ev_in, L.ev_done, L.ev_out}) if (e) (void)hipEventDestroy(e);
   }
+  if (h->s_h2d) { (void)hipStreamSynchronize(h->s_h2d); (void)hipStreamDestroy(h->s_h2d); }
+  if (h->s_d2h) { (void)hipStreamSynchronize(h->s_d2h); (void)hipStreamDestroy(h->s_d2h); }
+  if (h->ev_copy_tail) (void)hipEventDestroy(h->ev_copy_tail);
   void* pinned[] = {h->p_preds, h->p_probs, h->p_logits, h->p_mask, h->h_range};
   for (void* p : pinned) if (p) (void)hipHostFree(p);
   void* bufs[] = {h->d_w32, h->d_w16, h->d_bias, h->d_range};
@@ -1095,6 +1136,7 @@ int pclseg_sync(pclseg_handle* h) {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
   DeviceGuard guard(h->device);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->host_async_pending = false;
   bool fired = false;
   int rc = take_range_flag(h, &fired);
   if (rc || !fired) return rc;
@@ -1102,9 +1144,10 @@ int pclseg_sync(pclseg_handle* h) {
   // repair: re-run the last asynchronous call with exact float32 products (its buffers are the
   // caller's and must still be valid, as for any asynchronous call that has not been synchronised)
   const pclseg_handle::LastCall c = h->last;
-  rc = sweep(h, c.input, c.raw, c.mask_in, c.n, c.preds, c.probs, c.logits, c.mask_out, PCLSEG_MEM_DEVICE, true);
+  rc = sweep(h, c.input, c.raw, c.mask_in, c.n, c.preds, c.probs, c.logits, c.mask_out, c.mem, true);
   if (rc) { drain_after_error(h); return rc; }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->host_async_pending = false;
   return PCLSEG_OK;
 }
 

@@ -672,7 +672,8 @@ inline void assign_formats(Graph* g) {
     const Op& prod = g->ops[producer[t]];
     const Op& rd = g->ops[reader_op[t]];
     if (prod.fsq_fused) { g->tensors[t].fmt = FMT_S16; continue; }   // the fused squeeze writes split-f16 only
-    const bool narrow = prod.nsub == 1 ? (prod.pkh == 1 && prod.pkw == 1) : (prod.ow_mul == 2);  // 1x1 conv or up-conv
+    bool narrow = prod.nsub == 1 ? (prod.pkh == 1 && prod.pkw == 1) : (prod.ow_mul == 2);  // 1x1 conv or up-conv
+    if (s16 >= 2 && rd.kind == OP_HEAD) narrow = true;   // tuning aid: the head's input too
     if (!narrow || g->tensors[t].C % 8 != 0) continue;
     if (op_is_flat(rd) && rd.nsub == 1) continue;   // LDS-free 1x1 readers split in registers anyway
     g->tensors[t].fmt = FMT_S16;

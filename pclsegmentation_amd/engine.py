@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PCLSEG_LIB") or os.path.join(_HERE, "libpclseg.so")  
 
 OK = 0
 ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE, ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_ASYNC = 0, 1, 2
 FLAG_KEEP_ACTIVATIONS = 1
 FLAG_EXACT_F32 = 2
 FLAG_RANGE_FALLBACK = 4
@@ -213,9 +213,11 @@ def _checked(x, dtype, count, what, mem=None):
       raise ValueError("pclseg: %s must be contiguous" % what)
     if x.numel() < count:
       raise ValueError("pclseg: %s holds %d elements, the call needs %d" % (what, x.numel(), count))
+    if mem == MEM_HOST_ASYNC and not x.is_cuda and not x.is_pinned():
+      raise ValueError("pclseg: %s must be page-locked (pin_memory) for MEM_HOST_ASYNC" % what)
     if mem is not None and x.is_cuda != (mem == MEM_DEVICE):
       raise ValueError("pclseg: %s lives on %s but the call was made with mem=%s" % (
-        what, "the device" if x.is_cuda else "the host", "MEM_DEVICE" if mem == MEM_DEVICE else "MEM_HOST"))
+        what, "the device" if x.is_cuda else "the host", "MEM_DEVICE" if mem == MEM_DEVICE else "MEM_HOST[_ASYNC]"))
     return x
   return x   # raw integer address: the caller vouches for it
 

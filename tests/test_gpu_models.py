@@ -383,6 +383,17 @@ def test_host_boundary_pinned_and_pageable_agree_with_device(cuda):
       srt = np.sort(want_l, -1)
       decided = (srt[..., -1] - srt[..., -2]) > 1e-6
       assert np.array_equal(h_preds.numpy()[decided], want_p[decided])
+    if pinned:   # enqueue-only calls on page-locked buffers, two in a row without a wait in between
+      h_preds2, h_logits2 = mk(n, h, w, dtype=torch.int32), mk(n, h, w, mc.NUM_CLASS, dtype=torch.float32)
+      h_preds.zero_()
+      eng.forward_raw(h_raw, n, h_preds, None, h_logits, None, mem=E.MEM_HOST_ASYNC)
+      eng.forward_raw(h_raw, n, h_preds2, None, h_logits2, None, mem=E.MEM_HOST_ASYNC)
+      eng.sync()
+      for pp, ll in ((h_preds, h_logits), (h_preds2, h_logits2)):
+        assert np.array_equal(pp.numpy(), want_p) and np.array_equal(ll.numpy(), want_l)
+    else:
+      with pytest.raises(ValueError):
+        eng.forward_raw(h_raw, n, h_preds, None, None, None, mem=E.MEM_HOST_ASYNC)   # needs pinned buffers
     # the reference-shaped entry (normalised lidar + mask) through the same boundary
     h_lidar = mk(n, h, w, 6, dtype=torch.float32)
     h_lidar.copy_(torch.from_numpy(lidar.astype(np.float32)))
