@@ -10,7 +10,11 @@ all: $(LIB)
 $(LIB): $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
 	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/pclseg_api.hip
 
+# debug build with in-kernel phase timestamps (PCLSEG_STAMP=<layer> PCLSEG_LIB=.../libpclseg_stamps.so)
+stamps: $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
+	$(HIPCC) $(HIPFLAGS) -DPCLSEG_WITH_STAMPS -o pclsegmentation_amd/libpclseg_stamps.so $(CSRC)/pclseg_api.hip
+
 clean:
 	rm -f $(LIB)
 
-.PHONY: all clean
+.PHONY: all clean stamps

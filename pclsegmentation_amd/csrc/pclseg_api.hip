@@ -317,6 +317,46 @@ hipError_t launch_conv_pair(const Op& op, int epi, dim3 grid, size_t lds, hipStr
   return hipErrorInvalidValue;
 }
 
+#ifdef PCLSEG_WITH_STAMPS
+// Debug build (make stamps): on the 20th launch of the merged-pair kernel whose layer name contains
+// $PCLSEG_STAMP, thread 0 of every block stamps s_memtime at the phase boundaries; the destructor (after
+// the launch) prints the mean per-block duration of each phase in shader cycles.
+struct StampDump {
+  unsigned long long* buf = nullptr;
+  unsigned blocks = 0;
+  hipStream_t s;
+  std::string name;
+  StampDump(const Op& op, ConvArgs* a, dim3 grid, hipStream_t s_) : s(s_) {
+    static const char* want = getenv("PCLSEG_STAMP");
+    static unsigned long long* dbuf = nullptr;
+    static int count = 0;
+    a->stamps = nullptr;
+    if (!want || !op.pair || op.name().find(want) == std::string::npos || grid.x > 16384) return;
+    if (!dbuf) (void)hipMalloc((void**)&dbuf, (size_t)16384 * 8 * 8);
+    if (++count != 20) return;
+    (void)hipMemsetAsync(dbuf, 0, (size_t)grid.x * 64, s);
+    a->stamps = buf = dbuf;
+    blocks = grid.x;
+    name = op.name();
+  }
+  ~StampDump() {
+    if (!buf) return;
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)blocks * 8);
+    (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+    static const char* nm[8] = {"entry", "staged", "K(first half)", "epilogue/partial 1", "K(second half)", "epilogue/partial 2",
+                                "(loop exit)", "slab+reduce+store / end"};
+    double sum[8] = {0};
+    for (unsigned b = 0; b < blocks; ++b)
+      for (int i = 1; i < 8; ++i) sum[i] += (double)(long long)(h[b * 8 + i] - h[b * 8 + i - 1]);
+    double tot = 0;
+    for (int i = 1; i < 8; ++i) tot += sum[i] / blocks;
+    fprintf(stderr, "STAMPS %s: %u blocks, %.0f cycles per block\n", name.c_str(), blocks, tot);
+    for (int i = 1; i < 8; ++i) fprintf(stderr, "  %-26s %8.0f cycles  %5.1f %%\n", nm[i], sum[i] / blocks, 100.0 * sum[i] / blocks / tot);
+  }
+};
+#endif
+
 // Fill the geometry of `a` (tensor pointers already set) from `op` and launch.
 // w32 / w16 / bias are the bases the sub-op offsets are relative to.
 hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const float* w32,
@@ -420,7 +460,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   if (a.skx) lds += (size_t)9 * a.out_C * sizeof(float);   // fused skip branch weights behind the patch
   if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
     if (exact) return hipErrorInvalidValue;
-    lds = std::max(lds, (size_t)8 * op.mtw * 16 * op.fsq.nctp * 16 * sizeof(float));
+    lds = std::max(lds, (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float));   // rows padded by 4 floats
     if (lds > 160 * 1024) return hipErrorInvalidValue;
   } else if (lds > 64 * 1024) return hipErrorInvalidValue;
   // (the fused-skip-branch epilogue of fire13 needs more registers than the merged kernel has left)
@@ -441,6 +481,9 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
   }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
+#ifdef PCLSEG_WITH_STAMPS
+  StampDump stamp_dump(op, &a, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split
+#endif
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
   if (op.fsq_fused) {
     if (!pair) return hipErrorInvalidValue;

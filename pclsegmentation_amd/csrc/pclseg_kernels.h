@@ -77,6 +77,9 @@ struct ConvArgs {
   int in_s16;   // input tensor is in split-f16 pair format (see below), else float32
   int out_s16;  // write the output in split-f16 pair format
   unsigned* range_flag;  // sticky: set when a value that is split to f16 hi/lo has |v| >= 65504
+#ifdef PCLSEG_WITH_STAMPS
+  unsigned long long* stamps;   // debug build (make stamps): s_memtime at the phase boundaries, [block][8]
+#endif
   int wt;                // write-through output stores (see store_quad)
   // fused squeeze of the NEXT FIRE module (conv_kernel FSQ): packed fragments, bias, couts, cout groups
   const _Float16* fsq_w16;
@@ -181,6 +184,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int kThreads = NW * 64;
   const int tid = threadIdx.x;
+#ifdef PCLSEG_WITH_STAMPS
+  auto stamp = [&](int i) { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime(); };
+#else
+  auto stamp = [](int) {};
+#endif
+  stamp(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
@@ -641,6 +650,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       // on every launch)
       stage(0, cin8);
       __syncthreads();
+      stamp(1);
       // Every block of a launch starts at the same time; if all of them ran 3x3 -> store -> 1x1 ->
       // store in the same order, the whole chip would alternate between a matrix-core phase (HBM
       // idle) and a store burst (matrix cores idle).  Half of the blocks therefore take the halves in
@@ -664,8 +674,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
             for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         kloop(K, 0, cin8);
+        stamp(2 + 2 * half);
         if constexpr (FSQ == 0) {
           epilogue(K, acc);
+          stamp(3 + 2 * half);
         } else {
           // this half's channels -> partial squeeze sums.  K-step st of the partial GEMM covers the
           // wave's cout tiles 2st and 2st+1: lane (p, g) contributes k = (g, j): j < 4 -> channel
@@ -726,19 +738,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
               }
             }
           }
+          stamp(3 + 2 * half);
         }
       }
+      stamp(6);
       if constexpr (FSQ > 0) {
         // partial sums -> LDS slab [wave][MTW*16 px][Q] (the patch is dead once every wave is here),
         // then a fixed-order sum over the WN waves of each pixel group, squeeze bias + ReLU, split, store
-        constexpr int Q = FSQ * 16, PXW = MTW * 16;
+        // Slab rows are padded by 4 floats: with Q a multiple of 16 the 8 consecutive pixels one
+        // ds_write_b128 lane group covers would otherwise all start in the same bank (rows 64..256 B
+        // apart: an 8- to 16-way conflict that made this phase 29 % of the block).
+        constexpr int Q = FSQ * 16, PXW = MTW * 16, QS = Q + 4;
         float* slab = reinterpret_cast<float*>(smem_raw);
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
           for (int qt = 0; qt < FSQ; ++qt)
-            *reinterpret_cast<f32x4*>(slab + ((size_t)(wave * PXW + m * 16 + p) * Q + qt * 16 + 4 * g)) = acc2[m][qt];
+            *reinterpret_cast<f32x4*>(slab + ((size_t)(wave * PXW + m * 16 + p) * QS + qt * 16 + 4 * g)) = acc2[m][qt];
         __syncthreads();
         constexpr int WMc = NW / WN, QQ = Q / 4;
         for (int idx = tid; idx < WMc * PXW * QQ; idx += kThreads) {
@@ -747,7 +764,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           f32x4 sum = *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4);
 #pragma unroll
           for (int w = 0; w < WN; ++w)
-            sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * Q + qq * 4));
+            sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * QS + qq * 4));
 #pragma unroll
           for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.0f);
           const int seg = wmi * MTW + (pl >> 4), pp = pl & 15;
@@ -774,6 +791,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       }
       epilogue(S, acc);
     }
+    stamp(7);
     if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
   }
 }
