@@ -510,6 +510,48 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
                : launch_conv_cfg<false, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);
 }
 
+// 3x3 s(1,2) max-pool + 1x1 squeeze in one pass (Op::pool_fused); `Win` is the width BEFORE the pool.
+template <int NTW>
+hipError_t launch_pool_squeeze_n(dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+  if (lds > 64 * 1024) {
+    static bool raised = false;   // one attribute per instantiation
+    if (!raised) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_squeeze_kernel<NTW>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((pool_squeeze_kernel<NTW>), grid, dim3(kConvThreads), lds, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_pool_squeeze(const Op& op, int N, int H, int Win, ConvArgs a, const _Float16* w16,
+                               const float* bias, hipStream_t s) {
+  const SubOp& su = op.sub[0];
+  const int C = op.cin_t;
+  if (!w16 || op.nsub != 1 || C % 32 != 0 || (C & (C - 1)) != 0 || su.nctp < 1 || su.nctp > 4 || op.ck16 < 32)
+    return hipErrorInvalidValue;
+  int wo, pl;
+  same_pad(Win, 3, 2, &wo, &pl);
+  a.N = N; a.H = H; a.Win = Win; a.Wout = a.Wconv = wo; a.pl = pl;
+  a.Cin = C;
+  a.nsub = 1;
+  ConvSub& d = a.sub[0];
+  d.w32 = nullptr;
+  d.w16 = w16 + su.w16_off;
+  d.bias = bias + su.b_off;
+  d.Cout = su.cout; d.nctp = su.nctp; d.ny = 1; d.co_off = su.co_off; d.act = su.act;
+  const dim3 grid((unsigned)(N * ((H + kPoolSqRows - 1) / kPoolSqRows) * ((wo + 15) / 16)));
+  const size_t lds = (size_t)kPoolSqRows * 16 * (2 * C + kPadF16) * sizeof(_Float16);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  switch (su.nctp) {
+    case 1: return launch_pool_squeeze_n<1>(grid, lds, s, a);
+    case 2: return launch_pool_squeeze_n<2>(grid, lds, s, a);
+    case 3: return launch_pool_squeeze_n<3>(grid, lds, s, a);
+    default: return launch_pool_squeeze_n<4>(grid, lds, s, a);
+  }
+}
+
 hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {
   c.N = N; c.H = H; c.W = W;
   constexpr int kTH = 4, kCK = 64;  // 4 x 26 pixel tiles, 64-channel chunks, 512-thread blocks
@@ -600,7 +642,9 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
       if (op.res2 >= 0) { a.res2 = arena + g.tensors[op.res2].offset; a.res2_C = g.tensors[op.res2].C; }
       if (op.sk_in >= 0) { a.skx = arena + g.tensors[op.sk_in].offset; a.skw = h->d_bias + op.sk.b_off; }
     }
-    const hipError_t le = launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream);
+    const hipError_t le = op.pool_fused
+        ? (exact ? hipErrorInvalidValue : launch_pool_squeeze(op, cnt, ti.H, ti.W, a, h->d_w16, h->d_bias, stream))
+        : launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream);
     if (le != hipSuccess)
       return fail(h, PCLSEG_ERR_HIP, fmt("launch of '%s' failed (%s): block shape mtw=%d ntw=%d wn=%d nw=%d, pair=%d, fused squeeze=%d",
                                          op.name().c_str(), hipGetErrorString(le), op.mtw, op.ntw, op.wn, op.nw, (int)op.pair, (int)op.fsq_fused));

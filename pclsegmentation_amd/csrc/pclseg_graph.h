@@ -82,6 +82,9 @@ struct Op {
   int ck32 = 32;         // channels per LDS pass, exact-f32 mode
   int pool_kh = 1, pool_kw = 1;
   bool pair = false;     // FIRE expand pair run as merged blocks (conv_kernel PAIR), split-f16 mode
+  // 1x1 conv whose input is max-pooled 3x3 / strides (1,2) on the fly (pool_squeeze_kernel): `in` is
+  // the tensor BEFORE the pool, the pooled tensor is never written
+  bool pool_fused = false;
   // fused squeeze of the NEXT FIRE module (conv_kernel FSQ): this op writes fireN+1/squeeze instead
   // of its own output; `fsq` names the Keras tensors, fsq.w16_off / b_off locate the packed fragments
   bool fsq_fused = false;
@@ -415,6 +418,28 @@ class GraphBuilder {
     return op.out;
   }
 
+  // Can pool_squeeze_kernel take this pool + squeeze?  (power-of-two channel count, all couts in one block)
+  static bool pool_squeeze_ok(int C, int cout) { return C >= 32 && C <= 512 && (C & (C - 1)) == 0 && cout <= 64; }
+
+  // The last op is the 3x3 s(1,2) pool that produced `pooled`, and this 1x1 conv (+BN+ReLU) is its only
+  // reader: replace the pool by one op that pools while it loads (nets/SqueezeSegV2.py:295-296,301-302,305-306).
+  int pooled_squeeze(const std::string& name, int pooled, int cout, const std::string& bn) {
+    const Op pool_op = g_->ops.back();
+    g_->ops.pop_back();
+    const TensorInfo tp = g_->tensors[pooled];
+    g_->tensors[pooled].def_op = g_->tensors[pooled].last_op = -1;   // never materialised
+    Op op;
+    op.kind = OP_CONV;
+    op.in = pool_op.in;
+    op.cin_t = op.cin_k = tp.C;
+    op.pool_fused = true;
+    op.sub[0] = conv_sub(name, 1, 1, tp.C, cout, true, bn, 1, 0);
+    op.out = tensor(name, tp.H, tp.W, cout);
+    g_->alg_macs += (int64_t)tp.H * tp.W * tp.C * cout;
+    push(op);
+    return op.out;
+  }
+
   void head(const std::string& name, int in, int num_class) {
     const TensorInfo ti = g_->tensors[in];
     Op op;
@@ -467,6 +492,7 @@ inline void build_squeezesegv2(Graph* g) {
   // squeeze is computed by fireN's expand blocks and the expand output is never written (split-f16
   // arithmetic only; every intermediate stays observable with KEEP_ACTIVATIONS, which disables it)
   static const int fuse_env = getenv("PCLSEG_FUSE_SQ") ? atoi(getenv("PCLSEG_FUSE_SQ")) : 1;
+  static const int fuse_pool = getenv("PCLSEG_FUSE_POOL") ? atoi(getenv("PCLSEG_FUSE_POOL")) : 1;   // pool -> squeeze in one kernel
   static const int fuse_keep = getenv("PCLSEG_FUSE_KEEP") ? atoi(getenv("PCLSEG_FUSE_KEEP")) : 0;   // debug
   const bool fuse = fuse_env && !(g->desc.flags & (PCLSEG_FLAG_EXACT_F32 | PCLSEG_FLAG_RANGE_FALLBACK)) &&
                     (fuse_keep || !(g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS));
@@ -486,6 +512,9 @@ inline void build_squeezesegv2(Graph* g) {
       b.touch(s, last_expand);
       g->tensors[x].def_op = g->tensors[x].last_op = -1;   // never materialised
       g->alg_macs += (int64_t)tx.H * tx.W * tx.C * sq_c;
+    } else if (fuse && fuse_pool && !g->ops.empty() && g->ops.back().kind == OP_POOL && g->ops.back().out == x &&
+               g->ops.back().pool_kh == 3 && g->ops.back().sw == 2 && GraphBuilder::pool_squeeze_ok(g->tensors[x].C, sq_c)) {
+      s = b.pooled_squeeze(p + "/squeeze", x, sq_c, p + "/squeeze_bn");   // pool1/3/5 feed only this squeeze
     } else {
       s = b.conv(p + "/squeeze", x, 1, 1, sq_c, 1, true, p + "/squeeze_bn", 1);
     }

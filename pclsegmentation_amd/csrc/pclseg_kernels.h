@@ -972,6 +972,120 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
   if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
 
+// ---- 3x3 / strides (1,2) SAME max-pool fused into the 1x1 squeeze that is its only reader
+// (pool1 -> fire2, pool3 -> fire4, pool5 -> fire6; nets/SqueezeSegV2.py:295-306).  The pooled tensor is
+// never written.  A block owns 16 output columns x 4 rows x all C channels:
+//   pool phase   thread <-> (column, channel quad) exactly as maxpool3x3s2_kernel: 6 rows x 3 columns of
+//                16-byte loads, consecutive lanes on consecutive channels (a quarter-wave covers whole
+//                cache lines; loading in the MFMA operand layout instead — 16 lanes on 16 different
+//                pixels — issues 8x the cache-line requests and was bound by the L1 tag rate), column max
+//                then row max in registers, split to f16 hi/lo, 8-byte LDS writes [pixel][hi C | lo C];
+//   GEMM phase   wave w <-> output row w: B operands are two ds_read_b128 per 32-channel step, weights the
+//                packed fragments of conv1x1_direct_kernel, then bias + ReLU + split-f16 store.
+// Out-of-image taps are clamped onto an in-window pixel (a duplicate never changes a max).
+constexpr int kPoolSqRows = 4;
+template <int NTW>
+__global__ __launch_bounds__(kConvThreads) void pool_squeeze_kernel(const ConvArgs a) {
+  constexpr int ROWS = kPoolSqRows;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* xs = reinterpret_cast<_Float16*>(smem_raw);   // [ROWS*16 px][2*C + kPadF16]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const ConvSub& S = a.sub[0];
+  const int C = a.Cin, c4n = C >> 2, pstride = 2 * C + kPadF16;
+  const int cgn = (a.Wout + 15) >> 4, rbn = (a.H + ROWS - 1) / ROWS;
+  int unit = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = unit % cgn;
+  unit /= cgn;
+  const int h0 = (unit % rbn) * ROWS;
+  const int n = unit / rbn;
+  const float* base = a.in + (size_t)n * a.H * a.Win * C;
+  int rowoff[ROWS + 2];
+#pragma unroll
+  for (int r = 0; r < ROWS + 2; ++r) {
+    const int hh = h0 - 1 + r;
+    rowoff[r] = (hh < 0 ? 0 : hh >= a.H ? a.H - 1 : hh) * a.Win * C;
+  }
+  float vmax = 0.f;
+  const int lc4 = 31 - __builtin_clz(c4n);   // c4n is a power of two (host-checked)
+  for (int item = tid; item < 16 * c4n; item += kConvThreads) {
+    const int cl = item >> lc4, c4 = item & (c4n - 1);
+    const int wo = cg * 16 + cl;
+    int col[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ww = wo * 2 - a.pl + j;
+      col[j] = (ww < 0 ? 0 : ww >= a.Win ? a.Win - 1 : ww) * C + c4 * 4;
+    }
+    f32x4 rm[ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < ROWS + 2; ++r) {
+      const float* row = base + rowoff[r];
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + col[0]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + col[1]);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(row + col[2]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rm[r][e] = fmaxf(fmaxf(v0[e], v1[e]), v2[e]);
+    }
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(rm[m][e], rm[m + 1][e]), rm[m + 2][e]);
+      vmax = absmax4(vmax, v);
+      f16x4 hi, lo;
+      split4(v, hi, lo);
+      _Float16* d = xs + (m * 16 + cl) * pstride + c4 * 4;
+      *reinterpret_cast<f16x4*>(d) = hi;
+      *reinterpret_cast<f16x4*>(d + C) = lo;
+    }
+  }
+  __syncthreads();
+
+  const int p = lane & 15, g = lane >> 4;
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int nn = 0; nn < NTW; ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const _Float16* xrow = xs + (wave * 16 + p) * pstride + g * 8;
+  const _Float16* wbase = S.w16 + lane * 8;
+  const int nsteps = C >> 5;
+  for (int t = 0; t < nsteps; ++t) {
+    const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + t * 32);
+    const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + t * 32 + C);
+    const _Float16* wp = wbase + (size_t)t * S.nctp * 1024;
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn) {
+      const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+      const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+      acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[nn], 0, 0, 0);
+      acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[nn], 0, 0, 0);
+      acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[nn], 0, 0, 0);
+    }
+  }
+  const int wo = cg * 16 + p, h = h0 + wave;
+  if (wo < a.Wout && h < a.H) {
+    const size_t px = ((size_t)n * a.H + h) * a.Wout + wo;
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn) {
+      const int co = nn * 16 + g * 4;
+      if (co >= S.Cout) continue;
+      const f32x4 v = act4(acc[nn] + *reinterpret_cast<const f32x4*>(S.bias + co), S.act);
+      if (a.out_s16) {
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        vmax = absmax4(vmax, v);
+        _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + px * (size_t)(2 * a.out_C) + S.co_off + co;
+        *reinterpret_cast<f16x4*>(o16) = hi;
+        *reinterpret_cast<f16x4*>(o16 + a.out_C) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(a.out + px * a.out_C + S.co_off + co) = v;
+      }
+    }
+  }
+  if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
+}
+
 // ---- MaxPool kh x kw, strides (1, sw), TF SAME (padding never wins)            (K6, K7)
 // Generic fallback (stand-alone op API and shapes the fused kernels do not cover).
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in,

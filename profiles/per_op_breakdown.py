@@ -19,13 +19,21 @@ def fire(p, up=False, sq=True, fused=None):
          [p + "/expand" + ("+" + fused if fused else "")]
 
 
-def sequence(fused):
+def sequence(fused, pooled=False):
   """fused 0: every squeeze its own launch; 1: fireN's expand blocks also compute fireN+1's squeeze for
-  N = 4, 6, 7, 8, 9; 2: also for the FIREUP chain N = 10, 11, 12."""
-  ops = ["normalize", "conv1", "cam1", "pool1"] + fire("fire2") + ["cam2"] + fire("fire3") + ["cam3", "pool3"]
+  N = 4, 6, 7, 8, 9; 2: also for the FIREUP chain N = 10, 11, 12.  pooled: pool1/3/5 run inside
+  fire2/4/6's squeeze."""
+  def psq(n, f):
+    return ["pool%d+sq%d" % (n, n + 1)] + fire(f, sq=False) if pooled else ["pool%d" % n] + fire(f)
+  ops = ["normalize", "conv1", "cam1"] + psq(1, "fire2") + ["cam2"] + fire("fire3") + ["cam3"]
+  if fused and pooled:
+    ops += ["pool3+sq4"] + fire("fire4", sq=False, fused="sq5") + fire("fire5", sq=False)
+    ops += ["pool5+sq6"] + fire("fire6", sq=False, fused="sq7")
+  elif fused:
+    ops += ["pool3"] + fire("fire4", fused="sq5") + fire("fire5", sq=False) + ["pool5"]
+    ops += fire("fire6", fused="sq7")
   if fused:
-    ops += fire("fire4", fused="sq5") + fire("fire5", sq=False) + ["pool5"]
-    ops += fire("fire6", fused="sq7") + fire("fire7", sq=False, fused="sq8") + fire("fire8", sq=False, fused="sq9")
+    ops += fire("fire7", sq=False, fused="sq8") + fire("fire8", sq=False, fused="sq9")
     ops += fire("fire9", sq=False, fused="sq10")
     if fused == 2:
       ops += fire("fire10", True, sq=False, fused="sq11") + fire("fire11", True, sq=False, fused="sq12")
@@ -33,7 +41,7 @@ def sequence(fused):
     else:
       ops += fire("fire10", True, sq=False)
   else:
-    ops += fire("fire4") + fire("fire5") + ["pool5"]
+    ops += ["pool3"] + fire("fire4") + fire("fire5") + ["pool5"]
     for f in ("fire6", "fire7", "fire8", "fire9"):
       ops += fire(f)
     ops += fire("fire10", True)
@@ -48,7 +56,7 @@ if len(sys.argv) > 2:
   per = int(sys.argv[2])
 else:   # smallest period of the kernel-name sequence
   per = next((p for p in range(8, 80) if len(names) >= 3 * p and names[:2 * p] == names[p:3 * p]), 37)
-ops = {37: sequence(0), 32: sequence(1), 29: sequence(2)}.get(per, [])
+ops = {37: sequence(0), 32: sequence(1), 29: sequence(2), 26: sequence(2, True)}.get(per, [])
 agg = collections.defaultdict(list)
 for i, r in enumerate(rows):
   agg[i % per].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
