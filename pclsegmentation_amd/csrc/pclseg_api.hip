@@ -559,7 +559,16 @@ hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {
   c.tilesH = (H + kTH - 1) / kTH;
   c.tilesW = (W + kCamTW - 1) / kCamTW;
   const dim3 grid((unsigned)(N * c.tilesH * c.tilesW));
-  const size_t lds = (size_t)(kTH * kCamPW * kCK + kCK * R) * sizeof(float);
+  size_t lds = (size_t)(kTH * kCamPW * kCK + kCK * R) * sizeof(float);
+  if (c.sq_out) {   // fused squeeze (cam2 -> fire3): gated chunk as split-f16 behind the squeeze activations
+    const int segs = (kTH * kCamTW + 15) / 16;
+    lds = std::max(lds, (size_t)((kTH * kCamTW * R * 4 + 15) & ~15) + (size_t)segs * 16 * (2 * kCK + kPadF16) * sizeof(_Float16));
+    const int nq = (c.sq_C + 15) / 16;
+    if (C == 128 && nq == 1) hipLaunchKernelGGL((cam_kernel<128, 8, kTH, kCK, 1>), grid, dim3(8 * kCK), lds, s, c);
+    else if (C == 128 && nq == 2) hipLaunchKernelGGL((cam_kernel<128, 8, kTH, kCK, 2>), grid, dim3(8 * kCK), lds, s, c);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (C == 64) hipLaunchKernelGGL((cam_kernel<64, 4, kTH, kCK>), grid, dim3(8 * kCK), lds, s, c);
   else if (C == 128) hipLaunchKernelGGL((cam_kernel<128, 8, kTH, kCK>), grid, dim3(8 * kCK), lds, s, c);
   else return hipErrorInvalidValue;
@@ -614,8 +623,20 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
     }
     if (op.kind == OP_CAM) {
       CamArgs c;
+      memset(&c, 0, sizeof(c));
       c.x = in;
-      c.out = arena + g.tensors[op.out].offset;
+      if (op.fsq_fused) {   // cam2 -> fire3/squeeze in one kernel: op.out is the squeeze tensor
+        if (exact) return fail(h, PCLSEG_ERR_STATE, "internal: fused CAM squeeze in an exact-f32 sweep");
+        const TensorInfo& to = g.tensors[op.out];
+        c.sq_out = arena + to.offset;
+        c.sq_C = to.C;
+        c.sq_s16 = to.fmt == FMT_S16 ? 1 : 0;
+        c.sq_w16 = h->d_w16 + op.fsq.w16_off;
+        c.sq_bias = h->d_bias + op.fsq.b_off;
+        c.range_flag = h->d_range;
+      } else {
+        c.out = arena + g.tensors[op.out].offset;
+      }
       const int C = op.cin_t, R = C / 16;
       c.w1 = h->d_bias + op.sub[0].b_off; c.b1 = c.w1 + (size_t)C * R;
       c.w2 = h->d_bias + op.sub[1].b_off; c.b2 = c.w2 + (size_t)R * C;
@@ -1165,7 +1186,14 @@ int pclseg_finalize(pclseg_handle* h) {
       std::vector<double> scale, shift;
       fold_bn(su, f, &scale, &shift);
       pack_bias(su, shift, bias.data() + su.b_off);
-      pack_fsq(op, f, scale, w16.data() + su.w16_off);
+      if (op.kind == OP_CAM) {   // cam_kernel SQ: the fragments of a plain 1x1 conv over C channels, 64-channel chunks
+        Op as_conv;
+        as_conv.cin_t = as_conv.cin_k = op.cin_t;
+        as_conv.ck16 = 64;
+        pack_w16(as_conv, su, f, scale, w16.data() + su.w16_off);
+      } else {
+        pack_fsq(op, f, scale, w16.data() + su.w16_off);
+      }
     }
     for (int i = 0; i < op.nsub; ++i) {
       const SubOp& su = op.sub[i];

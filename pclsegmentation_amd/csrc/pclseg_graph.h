@@ -493,6 +493,7 @@ inline void build_squeezesegv2(Graph* g) {
   // arithmetic only; every intermediate stays observable with KEEP_ACTIVATIONS, which disables it)
   static const int fuse_env = getenv("PCLSEG_FUSE_SQ") ? atoi(getenv("PCLSEG_FUSE_SQ")) : 1;
   static const int fuse_pool = getenv("PCLSEG_FUSE_POOL") ? atoi(getenv("PCLSEG_FUSE_POOL")) : 1;   // pool -> squeeze in one kernel
+  static const int fuse_cam = getenv("PCLSEG_FUSE_CAM") ? atoi(getenv("PCLSEG_FUSE_CAM")) : 1;   // cam2 -> fire3/squeeze in one kernel
   static const int fuse_keep = getenv("PCLSEG_FUSE_KEEP") ? atoi(getenv("PCLSEG_FUSE_KEEP")) : 0;   // debug
   const bool fuse = fuse_env && !(g->desc.flags & (PCLSEG_FLAG_EXACT_F32 | PCLSEG_FLAG_RANGE_FALLBACK)) &&
                     (fuse_keep || !(g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS));
@@ -510,6 +511,18 @@ inline void build_squeezesegv2(Graph* g) {
       s = b.tensor(p + "/squeeze", tx.H, tx.W, sq_c);
       pe.out = s;
       b.touch(s, last_expand);
+      g->tensors[x].def_op = g->tensors[x].last_op = -1;   // never materialised
+      g->alg_macs += (int64_t)tx.H * tx.W * tx.C * sq_c;
+    } else if (fuse_prev && fuse && fuse_cam && !g->ops.empty() && g->ops.back().kind == OP_CAM && g->ops.back().out == x &&
+               g->tensors[x].C == 128 && sq_c <= 32) {
+      // cam2 -> fire3 (:297-298): the gated tile never leaves the CAM block, which writes fire3/squeeze
+      const TensorInfo tx = g->tensors[x];
+      Op& pc = g->ops.back();
+      pc.fsq = b.conv_sub(p + "/squeeze", 1, 1, tx.C, sq_c, true, p + "/squeeze_bn", 1, 0);
+      pc.fsq_fused = true;
+      s = b.tensor(p + "/squeeze", tx.H, tx.W, sq_c);
+      pc.out = s;
+      b.touch(s, (int)g->ops.size() - 1);
       g->tensors[x].def_op = g->tensors[x].last_op = -1;   // never materialised
       g->alg_macs += (int64_t)tx.H * tx.W * tx.C * sq_c;
     } else if (fuse && fuse_pool && !g->ops.empty() && g->ops.back().kind == OP_POOL && g->ops.back().out == x &&
@@ -542,7 +555,7 @@ inline void build_squeezesegv2(Graph* g) {
   x = pool("pool1", cam1);                                                                  // :295
   x = fire("fire2", x, 16, 64, 64, false, -1);
   x = cam("cam2", x);
-  x = fire("fire3", x, 16, 64, 64, false, -1);
+  x = fire("fire3", x, 16, 64, 64, false, -1, 0, true);
   const int cam3 = cam("cam3", x);                                                          // :299
   x = pool("pool3", cam3);                                                                  // :301
   x = fire("fire4", x, 32, 128, 128, false, -1);
@@ -707,6 +720,9 @@ inline void assign_formats(Graph* g) {
     if (op_is_flat(rd) && rd.nsub == 1) continue;   // LDS-free 1x1 readers split in registers anyway
     g->tensors[t].fmt = FMT_S16;
   }
+  for (const Op& op : g->ops)   // the squeeze a CAM block computes (cam_kernel SQ) feeds an expand pair's staging
+    if (op.kind == OP_CAM && op.fsq_fused && readers[op.out] == 1 && other[op.out] == 0 && g->tensors[op.out].C % 8 == 0)
+      g->tensors[op.out].fmt = FMT_S16;
   if (pair)
     for (Op& op : g->ops)
       if (op.kind == OP_CONV && op.nsub == 2 && op.ow_mul == 1 && op.pkh == 3 && op.sub[0].nkh == 1 &&
@@ -772,6 +788,13 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
     }
     if (op.kind == OP_CAM) {  // plain [C][R]+[R] and [R][C]+[C] float32 blocks
       const int C = op.cin_t, R = C / 16;
+      if (op.fsq_fused) {     // + the fused squeeze as 1x1 fragments [C/32 steps][tiles][hi|lo][lane][8]
+        op.fsq.nctp = (op.fsq.cout + 15) / 16;
+        op.fsq.w16_off = g->packed16_halfs;
+        g->packed16_halfs += (int64_t)(C / 32) * op.fsq.nctp * 1024;
+        op.fsq.b_off = g->packed_bias_floats;
+        g->packed_bias_floats += (int64_t)op.fsq.nctp * 16;
+      }
       op.sub[0].b_off = g->packed_bias_floats;
       g->packed_bias_floats += (int64_t)C * R + R;
       op.sub[1].b_off = g->packed_bias_floats;

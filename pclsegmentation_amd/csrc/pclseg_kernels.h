@@ -1130,6 +1130,13 @@ struct CamArgs {
   const float* w2;  // [R][C]  BN-folded excitation weights
   const float* b2;  // [C]
   int N, H, W, tilesH, tilesW;
+  // fused squeeze of the FIRE module that is this CAM's only reader (cam_kernel SQ > 0): out = nullptr,
+  // the gated tile goes through LDS to the matrix cores and only the squeeze output is written
+  const _Float16* sq_w16;   // packed 1x1 fragments [C/32 steps][SQ tiles][hi|lo][lane][8]
+  const float* sq_bias;     // [SQ*16]
+  float* sq_out;            // [N,H,W,sq_C] float32, or split-f16 pair format when sq_s16
+  int sq_C, sq_s16;
+  unsigned* range_flag;
 };
 
 // A block owns a TH x 26 pixel tile; its (TH+6) x 32 halo patch is swept in CK-channel chunks.
@@ -1187,7 +1194,11 @@ __device__ __forceinline__ float cam_reduce_scatter(float (&p)[R], int q) {
   return keep + dpp_read<kXor1>(send);   // lane holds index u (R = 8: bits 4,2,1; R = 4: bits 2,1)
 }
 
-template <int C, int R, int TH, int CK>
+// SQ > 0: the module's output feeds only the next FIRE squeeze (cam2 -> fire3, nets/SqueezeSegV2.py:297-298):
+// the gate pass writes each 64-channel chunk of the gated tile as split-f16 into LDS (the dead column-max
+// buffer), wave w < 7 accumulates pixel segment w x SQ cout tiles on the matrix cores, and the block
+// writes bias + ReLU of that instead of the 128-channel tensor.
+template <int C, int R, int TH, int CK, int SQ = 0>
 __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
   constexpr int TW = kCamTW, PW = kCamPW, PH = TH + 6, NCH = C / CK;
   constexpr int QP = CK / 4, LQ = QP == 32 ? 5 : QP == 16 ? 4 : 3;  // channel quads per chunk = lanes per pixel
@@ -1220,7 +1231,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
     }
   };
 
-  f32x4 xs[NCH][TH];  // this thread's tile pixels (rows h0.., column w), kept for the gate
+  f32x4 xs_reg[NCH][TH];  // this thread's tile pixels (rows h0.., column w), kept for the gate
   float sp[TH];
 #pragma unroll
   for (int r = 0; r < TH; ++r) sp[r] = 0.f;
@@ -1230,7 +1241,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
   for (int chunk = 0; chunk < NCH; ++chunk) {
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-      xs[chunk][r] = v[3 + r];
+      xs_reg[chunk][r] = v[3 + r];
     }
     {  // 7-tall running max: triples shared between neighbouring outputs (v_max3_f32)
       f32x4 t3[PH - 2];
@@ -1297,10 +1308,20 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
   __syncthreads();
 
   // gate: out = x * sigmoid(W2 . s + b2) on the register-resident tile pixels
-  if (interior && wok) {
-    float* outn = a.out + (size_t)n * a.H * a.W * C;
+  const bool active = interior && wok;
+  float* outn = a.out + (size_t)n * a.H * a.W * C;
+  // fused squeeze: gated chunk -> LDS [TH*TW px (+ pad to 16)][CK hi | CK lo | pad] behind s_lds
+  constexpr int kSegs = (TH * TW + 15) / 16, kXS = 2 * CK + kPadF16;
+  static_assert(SQ == 0 || kSegs <= 8, "one pixel segment per wave");
+  _Float16* xs = reinterpret_cast<_Float16*>(smem_raw + ((TH * TW * R * 4 + 15) & ~15));
+  const int lane = tid & 63, wave = tid >> 6;
+  f32x4 acc[SQ > 0 ? SQ : 1];
 #pragma unroll
-    for (int chunk = 0; chunk < NCH; ++chunk) {
+  for (int nn = 0; nn < (SQ > 0 ? SQ : 1); ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;
+#pragma unroll
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    if (active) {
       f32x4 w2r[R];
 #pragma unroll
       for (int rr = 0; rr < R; ++rr)
@@ -1309,7 +1330,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
         const int h = h0 + r;
-        if (h < a.H) {
+        if (SQ > 0 || h < a.H) {
           f32x4 z = bz;
 #pragma unroll
           for (int rr = 0; rr < R; rr += 4) {
@@ -1322,11 +1343,71 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e)  // sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, ~1 ulp each)
-            o[e] = xs[chunk][r][e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z[e]));
-          *reinterpret_cast<f32x4*>(outn + ((size_t)h * a.W + w) * C + chunk * CK + q * 4) = o;
+            o[e] = xs_reg[chunk][r][e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z[e]));
+          if constexpr (SQ > 0) {
+            if (h >= a.H) o = (f32x4){0.f, 0.f, 0.f, 0.f};   // (rows below the image: -inf * gate; never stored)
+            f16x4 hi, lo;
+            split4(o, hi, lo);
+            vmax = absmax4(vmax, o);
+            _Float16* d = xs + (r * TW + pc - 3) * kXS + q * 4;
+            *reinterpret_cast<f16x4*>(d) = hi;
+            *reinterpret_cast<f16x4*>(d + CK) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(outn + ((size_t)h * a.W + w) * C + chunk * CK + q * 4) = o;
+          }
         }
       }
     }
+    if constexpr (SQ > 0) {
+      __syncthreads();
+      if (wave < kSegs) {
+        const int p = lane & 15, g = lane >> 4;
+        const _Float16* xrow = xs + (wave * 16 + p) * kXS + g * 8;
+#pragma unroll
+        for (int t = 0; t < CK / 32; ++t) {
+          const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + t * 32);
+          const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + t * 32 + CK);
+          const _Float16* wp = a.sq_w16 + ((size_t)(chunk * (CK / 32) + t) * SQ) * 1024 + lane * 8;
+#pragma unroll
+          for (int nn = 0; nn < SQ; ++nn) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+            acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[nn], 0, 0, 0);
+            acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[nn], 0, 0, 0);
+            acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[nn], 0, 0, 0);
+          }
+        }
+      }
+      if (chunk + 1 < NCH) __syncthreads();
+    }
+  }
+  if constexpr (SQ > 0) {
+    const int p = lane & 15, g = lane >> 4;
+    const int i = wave * 16 + p;          // tile pixel of this lane's accumulator column
+    const int r = i / TW, c = i - r * TW;
+    const int h = h0 + r, wc = w0 + c;
+    if (wave < kSegs && i < TH * TW && h < a.H && wc < a.W) {
+      const size_t px = ((size_t)n * a.H + h) * a.W + wc;
+#pragma unroll
+      for (int nn = 0; nn < SQ; ++nn) {
+        const int co = nn * 16 + g * 4;
+        if (co >= a.sq_C) continue;
+        f32x4 v = acc[nn] + *reinterpret_cast<const f32x4*>(a.sq_bias + co);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        if (a.sq_s16) {
+          f16x4 hi, lo;
+          split4(v, hi, lo);
+          vmax = absmax4(vmax, v);
+          _Float16* o16 = reinterpret_cast<_Float16*>(a.sq_out) + px * (size_t)(2 * a.sq_C) + co;
+          *reinterpret_cast<f16x4*>(o16) = hi;
+          *reinterpret_cast<f16x4*>(o16 + a.sq_C) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(a.sq_out + px * a.sq_C + co) = v;
+        }
+      }
+    }
+    if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
   }
 }
 

@@ -19,13 +19,14 @@ def fire(p, up=False, sq=True, fused=None):
          [p + "/expand" + ("+" + fused if fused else "")]
 
 
-def sequence(fused, pooled=False):
+def sequence(fused, pooled=False, cam=False):
   """fused 0: every squeeze its own launch; 1: fireN's expand blocks also compute fireN+1's squeeze for
   N = 4, 6, 7, 8, 9; 2: also for the FIREUP chain N = 10, 11, 12.  pooled: pool1/3/5 run inside
-  fire2/4/6's squeeze."""
+  fire2/4/6's squeeze; cam: cam2's blocks compute fire3's squeeze."""
   def psq(n, f):
     return ["pool%d+sq%d" % (n, n + 1)] + fire(f, sq=False) if pooled else ["pool%d" % n] + fire(f)
-  ops = ["normalize", "conv1", "cam1"] + psq(1, "fire2") + ["cam2"] + fire("fire3") + ["cam3"]
+  ops = ["normalize", "conv1", "cam1"] + psq(1, "fire2")
+  ops += (["cam2+sq3"] + fire("fire3", sq=False) if cam else ["cam2"] + fire("fire3")) + ["cam3"]
   if fused and pooled:
     ops += ["pool3+sq4"] + fire("fire4", sq=False, fused="sq5") + fire("fire5", sq=False)
     ops += ["pool5+sq6"] + fire("fire6", sq=False, fused="sq7")
@@ -56,7 +57,7 @@ if len(sys.argv) > 2:
   per = int(sys.argv[2])
 else:   # smallest period of the kernel-name sequence
   per = next((p for p in range(8, 80) if len(names) >= 3 * p and names[:2 * p] == names[p:3 * p]), 37)
-ops = {37: sequence(0), 32: sequence(1), 29: sequence(2), 26: sequence(2, True)}.get(per, [])
+ops = {37: sequence(0), 32: sequence(1), 29: sequence(2), 26: sequence(2, True), 25: sequence(2, True, True)}.get(per, [])
 agg = collections.defaultdict(list)
 for i, r in enumerate(rows):
   agg[i % per].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_models.py::test_fused_squeeze_intermediates (run as a subprocess with
 PCLSEG_FUSE_KEEP=1, a debug switch that keeps the expand -> next-squeeze fusion ON together with
-PCLSEG_FLAG_KEEP_ACTIVATIONS): every fused squeeze output (pool -> squeeze and expand -> squeeze) and
+PCLSEG_FLAG_KEEP_ACTIVATIONS): every fused squeeze output (pool -> squeeze, CAM -> squeeze and expand -> squeeze) and
 the logits against the float64 oracle.
 Prints one line per tensor and exits non-zero on a mismatch.
 
@@ -31,6 +31,7 @@ names = [t[0] for t in eng.tensors()]
 W = O._W(model.weights, np.float64)
 bad = 0
 for src, dst in (("pool1", "fire2"), ("pool3", "fire4"), ("pool5", "fire6"),   # pool -> squeeze (pool_squeeze_kernel)
+                 ("cam2", "fire3"),                                              # CAM -> squeeze (cam_kernel SQ)
                  ("fire4", "fire5"), ("fire6", "fire7"), ("fire7", "fire8"), ("fire8", "fire9"), ("fire9", "fire10"),
                  ("fire10", "fire11"), ("fire11", "fire12"), ("fire12", "fire13")):
   if src in names and eng.tensors()[names.index(src)][1][0] > 0:
