@@ -331,7 +331,7 @@ struct StampDump {
     static unsigned long long* dbuf = nullptr;
     static int count = 0;
     a->stamps = nullptr;
-    if (!want || !op.pair || op.name().find(want) == std::string::npos || grid.x > 16384) return;
+    if (!want || op.name().find(want) == std::string::npos || grid.x > 16384) return;
     if (!dbuf) (void)hipMalloc((void**)&dbuf, (size_t)16384 * 8 * 8);
     if (++count != 20) return;
     (void)hipMemsetAsync(dbuf, 0, (size_t)grid.x * 64, s);
@@ -344,8 +344,10 @@ struct StampDump {
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h((size_t)blocks * 8);
     (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
-    static const char* nm[8] = {"entry", "staged", "K(first half)", "epilogue/partial 1", "K(second half)", "epilogue/partial 2",
-                                "(loop exit)", "slab+reduce+store / end"};
+    // merged pairs: staged | K | epilogue or partial squeeze | K | epilogue/partial | - | slab phase;
+    // other ops: staged chunk 0 | K chunk 0 | staged chunk 1 | K chunk 1 | (later chunks) | epilogue | end
+    static const char* nm[8] = {"entry", "staged", "K (first)", "epilogue 1 / staged 2", "K (second)", "epilogue 2 / more chunks",
+                                "loop exit / epilogue", "slab+reduce+store / end"};
     double sum[8] = {0};
     for (unsigned b = 0; b < blocks; ++b)
       for (int i = 1; i < 8; ++i) sum[i] += (double)(long long)(h[b * 8 + i] - h[b * 8 + i - 1]);

@@ -787,9 +787,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
         if (chunk) __syncthreads();
         stage(c8_0, ck8);
         __syncthreads();
+        stamp(chunk < 2 ? 1 + 2 * chunk : 5);
         kloop(S, chunk, ck8);
+        stamp(chunk < 2 ? 2 + 2 * chunk : 5);
       }
+      if (chunk < 2) { stamp(3); stamp(4); }
+      stamp(5);
       epilogue(S, acc);
+      stamp(6);
     }
     stamp(7);
     if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
