@@ -308,6 +308,30 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
   return hipErrorInvalidValue;
 }
 
+// merged FIREUP pair that up-convolves its own patch (conv_kernel UP): fire10 / fire11 / fire12 (with their
+// fused next squeeze and skip add) and fire13 (fused skip branch); (mtw, ntw, wn, nq, epi, up = C/16)
+#define PCLSEG_UP_CFGS(X) X(4, 1, 8, 2, 1, 4) X(4, 1, 4, 1, 1, 2) X(4, 1, 2, 1, 1, 1) X(4, 1, 2, 0, 3, 1)
+hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+  const int nq = op.fsq_fused ? a.fsq_q / 16 : 0;
+#define PCLSEG_X(M_, N_, W_, Q_, E_, U_) \
+  if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == 8 && nq == Q_ && epi == E_ && op.cin_t == 16 * U_) { \
+    auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_, U_>; \
+    if (lds > 64 * 1024) { \
+      static bool raised = false; \
+      if (!raised) { \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (e != hipSuccess) return e; \
+        raised = true; \
+      } \
+    } \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a); \
+    return hipGetLastError(); \
+  }
+  PCLSEG_UP_CFGS(PCLSEG_X)
+#undef PCLSEG_X
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_conv_pair(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
 #define PCLSEG_X(M_, N_, W_, NW_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == NW_) \
@@ -487,6 +511,14 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   StampDump stamp_dump(op, &a, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split
 #endif
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
+  if (op.up_fused) {   // `a.in` is the half-width squeeze tensor; Win is the up-convolved width
+    if (!pair || !a.in_s16 || !w16 || (Win & 1)) return hipErrorInvalidValue;
+    a.up_w16[0] = w16 + op.up[0].w16_off;
+    a.up_w16[1] = w16 + op.up[1].w16_off;
+    a.up_bias = bias + op.up[0].b_off;
+    a.up_Win = Win / 2;
+    a.up_nctp = op.up[0].nctp;
+  }
   if (op.fsq_fused) {
     if (!pair) return hipErrorInvalidValue;
     a.fsq_w16 = w16 + op.fsq.w16_off;
@@ -494,8 +526,9 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     a.fsq_q = op.fsq.nctp * 16;
     a.fsq_ncg = op.sub[0].nctp / op.ntw;
     a.flip_bit = -1;
-    return launch_conv_fsq(op, epi, grid, lds, s, a);
+    return op.up_fused ? launch_conv_up(op, epi, grid, lds, s, a) : launch_conv_fsq(op, epi, grid, lds, s, a);
   }
+
   if (pair) {
     static const int wt = getenv("PCLSEG_WT") ? atoi(getenv("PCLSEG_WT")) : 1;
     // half of the blocks of an 8-wave pair take the 1x1 half first (fire8/9/10: -1.3 .. -3.4 us; the
@@ -503,8 +536,9 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     static const int flip = getenv("PCLSEG_FLIP") ? atoi(getenv("PCLSEG_FLIP")) : 3;
     a.flip_bit = op.nw == 8 ? flip : -1;
     a.wt = (wt && !a.res1 && op.nw == 4) ? 1 : 0;   // pays for the 4-wave pairs that only write (see store_quad)
-    return launch_conv_pair(op, epi, grid, lds, s, a);
+    return op.up_fused ? launch_conv_up(op, epi, grid, lds, s, a) : launch_conv_pair(op, epi, grid, lds, s, a);
   }
+  if (op.up_fused) return hipErrorInvalidValue;
   if (op.kind == OP_HEAD)
     return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
                  : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);
@@ -667,7 +701,7 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
     }
     const hipError_t le = op.pool_fused
         ? (exact ? hipErrorInvalidValue : launch_pool_squeeze(op, cnt, ti.H, ti.W, a, h->d_w16, h->d_bias, stream))
-        : launch_conv(op, cnt, ti.H, ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream);
+        : launch_conv(op, cnt, ti.H, op.up_fused ? 2 * ti.W : ti.W, a, h->d_w32, h->d_w16, h->d_bias, exact, stream);
     if (le != hipSuccess)
       return fail(h, PCLSEG_ERR_HIP, fmt("launch of '%s' failed (%s): block shape mtw=%d ntw=%d wn=%d nw=%d, pair=%d, fused squeeze=%d",
                                          op.name().c_str(), hipGetErrorString(le), op.mtw, op.ntw, op.wn, op.nw, (int)op.pair, (int)op.fsq_fused));
@@ -1195,6 +1229,20 @@ int pclseg_finalize(pclseg_handle* h) {
         pack_w16(as_conv, su, f, scale, w16.data() + su.w16_off);
       } else {
         pack_fsq(op, f, scale, w16.data() + su.w16_off);
+      }
+    }
+    if (op.up_fused) {
+      if (!want16) return fail(h, PCLSEG_ERR_STATE, "internal: fused up-convolution in an exact-f32 plan");
+      for (int i = 0; i < 2; ++i) {
+        const SubOp& su = op.up[i];
+        FoldIn f;
+        f.kernel = W(su.name + "/kernel"); f.bias = W(su.name + "/bias");
+        if (!f.kernel || !f.bias)
+          return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", su.name.c_str()));
+        std::vector<double> scale, shift;
+        fold_bn(su, f, &scale, &shift);
+        pack_bias(su, shift, bias.data() + su.b_off);
+        pack_w16(op, su, f, scale, w16.data() + su.w16_off);
       }
     }
     for (int i = 0; i < op.nsub; ++i) {

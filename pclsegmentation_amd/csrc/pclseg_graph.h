@@ -85,6 +85,10 @@ struct Op {
   // 1x1 conv whose input is max-pooled 3x3 / strides (1,2) on the fly (pool_squeeze_kernel): `in` is
   // the tensor BEFORE the pool, the pooled tensor is never written
   bool pool_fused = false;
+  // FIREUP expand pair that up-convolves its own input patch (conv_kernel UP): `in` is the module's
+  // squeeze output at half the width, `up[parity]` are the transposed conv's two 2-tap sub-convs
+  bool up_fused = false;
+  SubOp up[2];
   // fused squeeze of the NEXT FIRE module (conv_kernel FSQ): this op writes fireN+1/squeeze instead
   // of its own output; `fsq` names the Keras tensors, fsq.w16_off / b_off locate the packed fragments
   bool fsq_fused = false;
@@ -730,6 +734,56 @@ inline void assign_formats(Graph* g) {
         op.pair = true;
 }
 
+// Recompute every tensor's first / last op from the op list (after ops were removed or rewired).
+inline void recompute_lifetimes(Graph* g) {
+  for (TensorInfo& t : g->tensors) t.def_op = t.last_op = -1;
+  auto touch = [&](int t, int i) {
+    if (t < 0) return;
+    TensorInfo& ti = g->tensors[t];
+    if (ti.def_op < 0) ti.def_op = i;
+    ti.last_op = std::max(ti.last_op, i);
+  };
+  for (size_t i = 0; i < g->ops.size(); ++i) {
+    const Op& op = g->ops[i];
+    touch(op.in, (int)i); touch(op.out, (int)i); touch(op.res1, (int)i); touch(op.res2, (int)i); touch(op.sk_in, (int)i);
+  }
+}
+
+// SqueezeSegV2's FIREUP modules (nets/SqueezeSegV2.py:191-199): squeeze -> Conv2DTranspose -> expand pair.
+// Where the pair runs as one merged block that holds every cout of its pixels (fire10/11/12 with their
+// fused next squeeze, fire13 with its fused skip branch) and both tensors are split-f16, the transposed
+// conv moves into the pair's staging (conv_kernel UP) and its launch and its output tensor disappear.
+inline void fuse_upconvs(Graph* g) {
+  static const int on = getenv("PCLSEG_FUSE_UP") ? atoi(getenv("PCLSEG_FUSE_UP")) : 1;
+  static const int fuse_keep = getenv("PCLSEG_FUSE_KEEP") ? atoi(getenv("PCLSEG_FUSE_KEEP")) : 0;   // debug (tests/fused_worker.py)
+  if (!on || (g->desc.flags & (PCLSEG_FLAG_EXACT_F32 | PCLSEG_FLAG_RANGE_FALLBACK))) return;
+  if ((g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS) && !fuse_keep) return;
+  std::vector<int> readers(g->tensors.size(), 0);
+  for (const Op& op : g->ops) {
+    if (op.in >= 0) readers[op.in]++;
+    if (op.res1 >= 0) readers[op.res1]++;
+    if (op.res2 >= 0) readers[op.res2]++;
+    if (op.sk_in >= 0) readers[op.sk_in]++;
+  }
+  bool changed = false;
+  for (size_t i = 0; i + 1 < g->ops.size(); ++i) {
+    const Op& d = g->ops[i];
+    Op& e = g->ops[i + 1];
+    const bool is_deconv = d.kind == OP_CONV && d.ow_mul == 2 && d.nsub == 2 && d.sub[0].deconv && d.res1 < 0 && d.sk_in < 0;
+    if (!is_deconv || e.kind != OP_CONV || e.in != d.out || readers[d.out] != 1) continue;
+    const int C = d.cin_t;
+    if (!e.pair || !(e.fsq_fused || e.sk_in >= 0) || d.sub[0].cout != C || (C != 16 && C != 32 && C != 64)) continue;
+    if (g->tensors[d.in].fmt != FMT_S16 || g->tensors[d.out].fmt != FMT_S16) continue;
+    e.up_fused = true;
+    e.up[0] = d.sub[0];
+    e.up[1] = d.sub[1];
+    e.in = d.in;
+    g->ops.erase(g->ops.begin() + (long)i);
+    changed = true;
+  }
+  if (changed) recompute_lifetimes(g);
+}
+
 inline int resolve_micro_batch(const pclseg_desc& d) {
   if (d.micro_batch > 0) return d.micro_batch;
   const int64_t px = (int64_t)d.height * d.width;
@@ -779,6 +833,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
   if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) build_squeezesegv2(g);
   else build_darknet(g, d->arch == PCLSEG_ARCH_DARKNET21 ? 21 : 53);
   assign_formats(g);
+  if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) fuse_upconvs(g);
   // packed-parameter geometry: exact-f32 fragments, split-f16 fragments, biases
   for (Op& op : g->ops) {
     if (op.kind == OP_POOL) continue;
@@ -812,6 +867,16 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
       g->packed16_halfs += fsq_w16_halfs(op);
       op.fsq.b_off = g->packed_bias_floats;
       g->packed_bias_floats += (int64_t)op.fsq.nctp * 16;
+    }
+    if (op.up_fused) {   // the transposed conv's two parities, packed like any 2-tap sub-conv of this op
+      for (int i = 0; i < 2; ++i) {
+        SubOp& su = op.up[i];
+        su.nctp = (su.cout + 15) / 16;
+        su.w16_off = g->packed16_halfs;
+        g->packed16_halfs += sub_w16_halfs(op, su);
+        su.b_off = g->packed_bias_floats;
+        g->packed_bias_floats += (int64_t)su.nctp * 16;
+      }
     }
     for (int i = 0; i < op.nsub; ++i) {
       SubOp& su = op.sub[i];

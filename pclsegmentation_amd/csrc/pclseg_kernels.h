@@ -85,6 +85,11 @@ struct ConvArgs {
   const _Float16* fsq_w16;
   const float* fsq_bias;
   int fsq_q, fsq_ncg;
+  // fused FIREUP transposed convolution (conv_kernel UP): `in` is the module's squeeze output at HALF the
+  // width (split-f16), the block deconvolves its patch while staging; packed fragments per output parity
+  const _Float16* up_w16[2];
+  const float* up_bias;
+  int up_Win, up_nctp;
   int flip_bit;          // merged pairs: blocks with this bit of blockIdx.x set run the 1x1 half first (-1: none)
   int skw_lds_off;       // byte offset of the fused skip branch's [9][out_C] weights in dynamic LDS
   ConvSub sub[2];
@@ -179,7 +184,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //   - each wave accumulates the partial squeeze over ITS channels (both halves), the partials of the
 //     WN waves that share a pixel group are summed through LDS in a fixed order (deterministic), then
 //     bias + ReLU + split + store.
-template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0>
+// UP = C/16 > 0 (merged pair of a FIREUP module, C = squeeze channels): the module's Conv2DTranspose
+// (1,4)/(1,2) + ReLU (nets/SqueezeSegV2.py:176-183,194) runs inside the staging: instead of copying an
+// up-convolved patch from memory, the waves compute it — 16 patch pixels of one output parity per MFMA
+// tile, K = 2 taps x C straight from the half-width squeeze tensor — and write it to LDS in the staged
+// split-f16 layout.  Four launches and the four up-convolved tensors disappear.
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0, int UP = 0>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int kThreads = NW * 64;
@@ -587,6 +597,66 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       }
     };
 
+    // FIREUP: up-convolve the patch from the half-width squeeze tensor (see UP above).  Output column w
+    // = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1) with the kernel taps the
+    // packed fragments of that parity carry; pixels outside the image are the expand conv's zero padding.
+    auto stage_up = [&]() {
+      constexpr int NCT = UP > 0 ? UP : 1;
+      constexpr int C = 16 * NCT, ck8 = C >> 3, nk = 2 * ck8, nsteps = NCT;   // (host-checked: a.Cin == 16 * UP)
+      const int npc2 = a.PW >> 1;                       // patch columns of one parity (PW is even)
+      const int per = a.PH * npc2, upp = (per + 15) >> 4;
+      const int inv_np = (65536 + npc2 - 1) / npc2;
+      const _Float16* in16 = reinterpret_cast<const _Float16*>(a.in) + (size_t)n * a.H * a.up_Win * (size_t)(2 * C);
+      for (int u = wave; u < 2 * upp; u += NW) {
+        const int parity = u >= upp ? 1 : 0;
+        const int l = (u - parity * upp) * 16 + p;
+        const bool lv = l < per;
+        const int pr = __mul24(l, inv_np) >> 16;
+        const int pc = 2 * (l - __mul24(pr, npc2)) + ((parity ^ wbase) & 1);
+        const int h = hbase + pr, w = wbase + pc;
+        const bool pv = lv && h >= 0 && h < a.H && w >= 0 && w < a.Win;
+        const int j = w >> 1;
+        f32x4 au[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) au[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const _Float16* wq = a.up_w16[parity] + lane * 8;
+#pragma unroll
+        for (int s = 0; s < nsteps; ++s) {
+          const int kidx = 4 * s + g;
+          const int tap = kidx >= ck8 ? 1 : 0;
+          const int col = j - 1 + parity + tap;
+          const bool ok = pv && kidx < nk && col >= 0 && col < a.up_Win;
+          const _Float16* src = ok ? in16 + ((size_t)h * a.up_Win + col) * (size_t)(2 * C) + (kidx - tap * ck8) * 8 : in16;
+          f16x8 xh = *reinterpret_cast<const f16x8*>(src);
+          f16x8 xl = *reinterpret_cast<const f16x8*>(src + C);
+          if (!ok) { xh = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; xl = xh; }
+          const _Float16* wp = wq + (size_t)s * a.up_nctp * 1024;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + ct * 1024);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + ct * 1024 + 512);
+            au[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, au[ct], 0, 0, 0);
+            au[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, au[ct], 0, 0, 0);
+            au[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, au[ct], 0, 0, 0);
+          }
+        }
+        if (lv) {
+          _Float16* d = sm + (pr * a.PW + pc) * CSh + g * 4;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 v = au[ct] + *reinterpret_cast<const f32x4*>(a.up_bias + ct * 16 + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
+            vmax = absmax4(vmax, v);
+            f16x4 hi, lo;
+            split4(v, hi, lo);
+            *reinterpret_cast<f16x4*>(d + ct * 16) = hi;
+            *reinterpret_cast<f16x4*>(d + ct * 16 + plane) = lo;
+          }
+        }
+      }
+    };
+
     auto kloop = [&](const ConvSub& K, const int chunk, const int ck8) {
         const int ntaps = K.nkh * K.nkw;
         const int steps_full = (ntaps * ck8_full + 3) >> 2;
@@ -648,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       // same staged patch) through the same accumulators — ONE instance of the K loop and of the
       // epilogue, run twice (code size: a kernel that does not fit the instruction cache pays for it
       // on every launch)
-      stage(0, cin8);
+      if constexpr (UP > 0) stage_up(); else stage(0, cin8);
       __syncthreads();
       stamp(1);
       // Every block of a launch starts at the same time; if all of them ran 3x3 -> store -> 1x1 ->

@@ -19,10 +19,11 @@ def fire(p, up=False, sq=True, fused=None):
          [p + "/expand" + ("+" + fused if fused else "")]
 
 
-def sequence(fused, pooled=False, cam=False):
+def sequence(fused, pooled=False, cam=False, up=True):
   """fused 0: every squeeze its own launch; 1: fireN's expand blocks also compute fireN+1's squeeze for
   N = 4, 6, 7, 8, 9; 2: also for the FIREUP chain N = 10, 11, 12.  pooled: pool1/3/5 run inside
-  fire2/4/6's squeeze; cam: cam2's blocks compute fire3's squeeze."""
+  fire2/4/6's squeeze; cam: cam2's blocks compute fire3's squeeze; up=False: the FIREUP pairs
+  up-convolve their own patch (no upconv launches)."""
   def psq(n, f):
     return ["pool%d+sq%d" % (n, n + 1)] + fire(f, sq=False) if pooled else ["pool%d" % n] + fire(f)
   ops = ["normalize", "conv1", "cam1"] + psq(1, "fire2")
@@ -37,8 +38,8 @@ def sequence(fused, pooled=False, cam=False):
     ops += fire("fire7", sq=False, fused="sq8") + fire("fire8", sq=False, fused="sq9")
     ops += fire("fire9", sq=False, fused="sq10")
     if fused == 2:
-      ops += fire("fire10", True, sq=False, fused="sq11") + fire("fire11", True, sq=False, fused="sq12")
-      ops += fire("fire12", True, sq=False, fused="sq13") + fire("fire13", True, sq=False)
+      ops += fire("fire10", up, sq=False, fused="sq11") + fire("fire11", up, sq=False, fused="sq12")
+      ops += fire("fire12", up, sq=False, fused="sq13") + fire("fire13", up, sq=False)
     else:
       ops += fire("fire10", True, sq=False)
   else:
@@ -57,7 +58,7 @@ if len(sys.argv) > 2:
   per = int(sys.argv[2])
 else:   # smallest period of the kernel-name sequence
   per = next((p for p in range(8, 80) if len(names) >= 3 * p and names[:2 * p] == names[p:3 * p]), 37)
-ops = {37: sequence(0), 32: sequence(1), 29: sequence(2), 26: sequence(2, True), 25: sequence(2, True, True)}.get(per, [])
+ops = {37: sequence(0), 32: sequence(1), 29: sequence(2), 26: sequence(2, True), 25: sequence(2, True, True), 21: sequence(2, True, True, False)}.get(per, [])
 agg = collections.defaultdict(list)
 for i, r in enumerate(rows):
   agg[i % per].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

@@ -409,7 +409,8 @@ def test_host_boundary_pinned_and_pageable_agree_with_device(cuda):
 def test_fused_squeeze_intermediates(cuda, h, w):
   """fire4/6/7/8/9's and (after their skip add) fire10/11/12's expand blocks also compute the NEXT
   module's squeeze and never write their own output (conv_kernel FSQ); pool1/3/5 are taken while
-  fire2/4/6's squeeze loads its input (pool_squeeze_kernel); cam2's block computes fire3's squeeze.  KEEP_ACTIVATIONS normally switches that fusion off, so this runs a
+  fire2/4/6's squeeze loads its input (pool_squeeze_kernel); cam2's block computes fire3's squeeze;
+  the FIREUP pairs up-convolve their own input patch (conv_kernel UP).  KEEP_ACTIVATIONS normally switches that fusion off, so this runs a
   worker with the debug switch PCLSEG_FUSE_KEEP=1 and compares every fused squeeze output and the
   logits with the float64 oracle, on shapes with ragged 64-pixel tiles on both axes."""
   import subprocess
@@ -422,11 +423,11 @@ def test_fused_squeeze_intermediates(cuda, h, w):
 
 
 def test_fusion_is_active_by_default_and_off_for_debug_reads(cuda):
-  """The default SqueezeSegV2 plan launches 25 kernels per micro-batch (37 without the nine fused
-  squeezes and the three fused pools); KEEP_ACTIVATIONS / exact-f32 / range-fallback plans keep the 37-launch graph."""
+  """The default SqueezeSegV2 plan launches 21 kernels per micro-batch (37 without the nine fused
+  squeezes, the three fused pools and the four fused up-convolutions); KEEP_ACTIVATIONS / exact-f32 / range-fallback plans keep the 37-launch graph."""
   mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
   d = E.make_desc("squeezesegv2", 32, 240, 11, 10, mc.INPUT_MEAN, mc.INPUT_STD)
-  assert E.plan(d)["num_ops"] == 24           # + the normalise launch = 25
+  assert E.plan(d)["num_ops"] == 20           # + the normalise launch = 21
   for flags in (E.FLAG_KEEP_ACTIVATIONS, E.FLAG_EXACT_F32, E.FLAG_RANGE_FALLBACK):
     d = E.make_desc("squeezesegv2", 32, 240, 11, 10, mc.INPUT_MEAN, mc.INPUT_STD, flags=flags)
     assert E.plan(d)["num_ops"] == 36
