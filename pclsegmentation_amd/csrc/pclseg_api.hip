@@ -484,6 +484,11 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   lds = (lds + 15) & ~(size_t)15;
   a.skw_lds_off = (int)lds;
   if (a.skx) lds += (size_t)9 * a.out_C * sizeof(float);   // fused skip branch weights behind the patch
+  if (op.up_fused) {   // half-width source patch of the fused up-convolution behind that: PH x (PW/2 + 1) pixels x [hi C | lo C | pad]
+    lds = (lds + 15) & ~(size_t)15;
+    a.up_lds_off = (int)lds;
+    lds += (size_t)a.PH * (a.PW / 2 + 1) * (2 * op.cin_t + kPadF16) * sizeof(_Float16);
+  }
   if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
     if (exact) return hipErrorInvalidValue;
     lds = std::max(lds, (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float));   // rows padded by 4 floats

@@ -90,6 +90,7 @@ struct ConvArgs {
   const _Float16* up_w16[2];
   const float* up_bias;
   int up_Win, up_nctp;
+  int up_lds_off;        // byte offset of the source-patch copy in dynamic LDS
   int flip_bit;          // merged pairs: blocks with this bit of blockIdx.x set run the 1x1 half first (-1: none)
   int skw_lds_off;       // byte offset of the fused skip branch's [9][out_C] weights in dynamic LDS
   ConvSub sub[2];
@@ -601,58 +602,82 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
     // = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1) with the kernel taps the
     // packed fragments of that parity carry; pixels outside the image are the expand conv's zero padding.
     auto stage_up = [&]() {
+      // (1) the source patch — PH rows x (PW/2 + 1) half-width columns, zero outside the image — is copied
+      //     to LDS behind the main patch, 16-byte units, consecutive lanes on consecutive bytes;
+      // (2) wave <-> (output parity, 16-cout tile): its 2 x UP weight fragments are fetched once (in flight
+      //     during (1)) and stay in registers while it walks the 16-pixel units of that parity, B operands
+      //     from the LDS copy (units are dealt to the NSL waves that share a pair when 2*UP < NW).
       constexpr int NCT = UP > 0 ? UP : 1;
       constexpr int C = 16 * NCT, ck8 = C >> 3, nk = 2 * ck8, nsteps = NCT;   // (host-checked: a.Cin == 16 * UP)
+      constexpr int NPAIR = 2 * NCT, NSL = NW / NPAIR > 0 ? NW / NPAIR : 1;
+      constexpr int SS = 2 * C + kPadF16;               // halfs per source pixel: [hi C | lo C | pad]
+      constexpr int UPP = 2 * C / 8;                    // 16-byte units per source pixel (power of two)
+      const int pairi = wave % NPAIR, slice = wave / NPAIR;
+      const int parity = pairi / NCT, ct = pairi - parity * NCT;
       const int npc2 = a.PW >> 1;                       // patch columns of one parity (PW is even)
+      const int SC = npc2 + 1;                          // source columns: j0 .. j0 + npc2
+      const int j0 = (wbase - 1) >> 1;                  // = w0/2 - 1 (wbase = w0 - 1 is odd)
+      _Float16* src_lds = reinterpret_cast<_Float16*>(smem_raw + a.up_lds_off);
+      f16x8 wh[nsteps], wl[nsteps];
+      {
+        const _Float16* wq = a.up_w16[parity] + ct * 1024 + lane * 8;
+#pragma unroll
+        for (int s = 0; s < nsteps; ++s) {
+          wh[s] = *reinterpret_cast<const f16x8*>(wq + (size_t)s * a.up_nctp * 1024);
+          wl[s] = *reinterpret_cast<const f16x8*>(wq + (size_t)s * a.up_nctp * 1024 + 512);
+        }
+      }
+      const f32x4 ub = *reinterpret_cast<const f32x4*>(a.up_bias + ct * 16 + g * 4);
+      {
+        const _Float16* in16 = reinterpret_cast<const _Float16*>(a.in) + (size_t)n * a.H * a.up_Win * (size_t)(2 * C);
+        const int nunits = a.PH * SC * UPP;
+        const int inv_sc = (65536 + SC - 1) / SC;
+        for (int i = tid; i < nunits; i += kThreads) {
+          const int px = i / UPP, un = i - px * UPP;    // UPP is a power of two
+          const int r = __mul24(px, inv_sc) >> 16, c = px - __mul24(r, SC);
+          const int h = hbase + r, col = j0 + c;
+          const bool ok = h >= 0 && h < a.H && col >= 0 && col < a.up_Win;
+          f16x8 v = *reinterpret_cast<const f16x8*>(ok ? in16 + ((size_t)h * a.up_Win + col) * (size_t)(2 * C) + un * 8 : in16);
+          if (!ok) v = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          *reinterpret_cast<f16x8*>(src_lds + px * SS + un * 8) = v;
+        }
+      }
+      __syncthreads();
       const int per = a.PH * npc2, upp = (per + 15) >> 4;
       const int inv_np = (65536 + npc2 - 1) / npc2;
-      const _Float16* in16 = reinterpret_cast<const _Float16*>(a.in) + (size_t)n * a.H * a.up_Win * (size_t)(2 * C);
-      for (int u = wave; u < 2 * upp; u += NW) {
-        const int parity = u >= upp ? 1 : 0;
-        const int l = (u - parity * upp) * 16 + p;
+      if (slice < NSL)
+      for (int u = slice; u < upp; u += NSL) {
+        const int l = u * 16 + p;
         const bool lv = l < per;
-        const int pr = __mul24(l, inv_np) >> 16;
-        const int pc = 2 * (l - __mul24(pr, npc2)) + ((parity ^ wbase) & 1);
+        const int pr = lv ? __mul24(l, inv_np) >> 16 : 0;
+        const int k2 = lv ? l - __mul24(pr, npc2) : 0;
+        const int pc = 2 * k2 + ((parity ^ wbase) & 1);
         const int h = hbase + pr, w = wbase + pc;
         const bool pv = lv && h >= 0 && h < a.H && w >= 0 && w < a.Win;
-        const int j = w >> 1;
-        f32x4 au[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) au[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const _Float16* wq = a.up_w16[parity] + lane * 8;
+        // source column of tap 0 relative to j0: (w >> 1) - 1 + parity - j0
+        const int c0 = ((w >> 1) - 1 + parity) - j0;
+        f32x4 au = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < nsteps; ++s) {
           const int kidx = 4 * s + g;
           const int tap = kidx >= ck8 ? 1 : 0;
-          const int col = j - 1 + parity + tap;
-          const bool ok = pv && kidx < nk && col >= 0 && col < a.up_Win;
-          const _Float16* src = ok ? in16 + ((size_t)h * a.up_Win + col) * (size_t)(2 * C) + (kidx - tap * ck8) * 8 : in16;
-          f16x8 xh = *reinterpret_cast<const f16x8*>(src);
-          f16x8 xl = *reinterpret_cast<const f16x8*>(src + C);
-          if (!ok) { xh = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; xl = xh; }
-          const _Float16* wp = wq + (size_t)s * a.up_nctp * 1024;
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + ct * 1024);
-            const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + ct * 1024 + 512);
-            au[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, au[ct], 0, 0, 0);
-            au[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, au[ct], 0, 0, 0);
-            au[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, au[ct], 0, 0, 0);
-          }
+          const _Float16* sp = src_lds + (pr * SC + c0 + tap) * SS + (kidx - tap * ck8) * 8;
+          const f16x8 xh = *reinterpret_cast<const f16x8*>(sp);
+          const f16x8 xl = *reinterpret_cast<const f16x8*>(sp + C);
+          au = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], xh, au, 0, 0, 0);
+          au = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xl, au, 0, 0, 0);
+          au = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh, au, 0, 0, 0);
         }
         if (lv) {
-          _Float16* d = sm + (pr * a.PW + pc) * CSh + g * 4;
+          f32x4 v = au + ub;
 #pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            f32x4 v = au[ct] + *reinterpret_cast<const f32x4*>(a.up_bias + ct * 16 + g * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
-            vmax = absmax4(vmax, v);
-            f16x4 hi, lo;
-            split4(v, hi, lo);
-            *reinterpret_cast<f16x4*>(d + ct * 16) = hi;
-            *reinterpret_cast<f16x4*>(d + ct * 16 + plane) = lo;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
+          vmax = absmax4(vmax, v);
+          f16x4 hi, lo;
+          split4(v, hi, lo);
+          _Float16* d = sm + (pr * a.PW + pc) * CSh + ct * 16 + g * 4;
+          *reinterpret_cast<f16x4*>(d) = hi;
+          *reinterpret_cast<f16x4*>(d + plane) = lo;
         }
       }
     };
