@@ -1248,50 +1248,35 @@ struct CamArgs {
 // 7x7 max is separable and associative, so it is bit-identical to the 49-tap window.
 constexpr int kCamTW = 26, kCamPW = 32;
 
-// Cross-lane sum of p[] over the QP (8 or 16) lanes of a pixel on the DPP network (one VALU
-// instruction per exchange, no LDS round trip as with ds_bpermute).  The lanes of a pixel are
-// one DPP row (QP = 16) or half a row (QP = 8).  Pairings: row_mirror (i <-> 15-i), row_half_mirror
-// (i <-> 7-i), quad_perm [2,3,0,1] and [1,0,3,2]; each step either adds the partner's copy
-// (all-reduce) or keeps one half of the values and adds the partner's other half
-// (reduce-scatter).  `u` is the lane's index among the lanes that still hold distinct data.
-// Returns, in lane q < R, the total of p[q]; must be called from convergent code.
+// Cross-lane sum over the 16 lanes of a pixel on the DPP network (one VALU instruction per exchange, no
+// LDS round trip as with ds_bpermute): recursive halving — mirror / half-mirror / quad-perm pairings, each
+// step keeps half of the values and adds the partner's copy of them.  To keep every step the SAME register
+// pattern in every lane (no per-lane selects), lane q stores partial sum number v in slot v ^ L,
+// L = q & (R-1): a partner is always lane L ^ mask, so "my slot s pairs with its slot s ^ mask".
+// The caller fills p[s] with the partial of squeeze channel s ^ L (it reads its weights in that order).
+// Returns, in every lane, the total of squeeze channel q & (R-1); must be called from convergent code.
 template <int CTRL>
 __device__ __forceinline__ float dpp_read(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
-template <int R, int QP>
-__device__ __forceinline__ float cam_reduce_scatter(float (&p)[R], int q) {
-  static_assert((R == 4 || R == 8) && (QP == 8 || QP == 16), "unsupported CAM geometry");
+template <int R>
+__device__ __forceinline__ float cam_reduce_scatter(const float (&p)[R]) {
+  static_assert(R == 4 || R == 8, "unsupported CAM geometry");
   constexpr int kRowMirror = 0x140, kHalfMirror = 0x141, kXor2 = 0x4E, kXor1 = 0xB1;
-  int u = q;
-  if constexpr (QP == 16) {
+  float a1[R];      // lanes q and 15-q (L ^ (R-1)) combined: all R values stay
 #pragma unroll
-    for (int i = 0; i < R; ++i) p[i] += dpp_read<kRowMirror>(p[i]);
-    u = (u & 8) ? 15 - u : u;
-  }
+  for (int i = 0; i < R; ++i) a1[i] = p[i] + dpp_read<kRowMirror>(p[i ^ (R - 1)]);
   float k4[4];
-  if constexpr (R == 8) {
+  if constexpr (R == 8) {     // lanes u and 7-u (L ^ 7): keep slots 0..3
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float send = (u & 4) ? p[i] : p[4 + i];
-      const float keep = (u & 4) ? p[4 + i] : p[i];
-      k4[i] = keep + dpp_read<kHalfMirror>(send);   // partner 7-u is in the other half
-    }
-  } else {
+    for (int i = 0; i < 4; ++i) k4[i] = a1[i] + dpp_read<kHalfMirror>(a1[7 - i]);
+  } else {                    // four values over eight lanes: one more full exchange (L ^ 3)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k4[i] = p[i] + dpp_read<kHalfMirror>(p[i]);
-    u = (u & 4) ? 7 - u : u;
+    for (int i = 0; i < 4; ++i) k4[i] = a1[i] + dpp_read<kHalfMirror>(a1[3 - i]);
   }
-  float k2[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float send = (u & 2) ? k4[i] : k4[2 + i];
-    const float keep = (u & 2) ? k4[2 + i] : k4[i];
-    k2[i] = keep + dpp_read<kXor2>(send);
-  }
-  const float send = (u & 1) ? k2[0] : k2[1];
-  const float keep = (u & 1) ? k2[1] : k2[0];
-  return keep + dpp_read<kXor1>(send);   // lane holds index u (R = 8: bits 4,2,1; R = 4: bits 2,1)
+  const float k20 = k4[0] + dpp_read<kXor2>(k4[2]);   // L ^ 2: keep slots 0, 1
+  const float k21 = k4[1] + dpp_read<kXor2>(k4[3]);
+  return k20 + dpp_read<kXor1>(k21);                  // L ^ 1: keep slot 0 = value L
 }
 
 // SQ > 0: the module's output feeds only the next FIRE squeeze (cam2 -> fire3, nets/SqueezeSegV2.py:297-298):
@@ -1301,7 +1286,8 @@ __device__ __forceinline__ float cam_reduce_scatter(float (&p)[R], int q) {
 template <int C, int R, int TH, int CK, int SQ = 0>
 __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
   constexpr int TW = kCamTW, PW = kCamPW, PH = TH + 6, NCH = C / CK;
-  constexpr int QP = CK / 4, LQ = QP == 32 ? 5 : QP == 16 ? 4 : 3;  // channel quads per chunk = lanes per pixel
+  constexpr int QP = CK / 4, LQ = 4;  // channel quads per chunk = lanes per pixel = one DPP row
+  static_assert(QP == 16, "cam_reduce_scatter works on one 16-lane DPP row per pixel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* colmax = reinterpret_cast<float*>(smem_raw);  // [TH][PW][CK]
   float* w1c = colmax + TH * PW * CK;                  // [CK][R]
@@ -1314,20 +1300,20 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
   const int n = tile / a.tilesH;
   const int h0 = thi * TH, w0 = twi * TW;
   const float* xn = a.x + (size_t)n * a.H * a.W * C;
-  const f32x4 ninf = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   const int w = w0 - 3 + pc;
   const bool wok = w >= 0 && w < a.W;
   const bool interior = pc >= 3 && pc < 3 + TW;
+  // out-of-image taps are clamped onto the nearest image pixel: it lies inside every 7x7 window that
+  // would have seen the padding, and a duplicate never changes a max (no per-load select)
+  const int wcl = w < 0 ? 0 : w >= a.W ? a.W - 1 : w;
 
   f32x4 v[PH];
   auto load_chunk = [&](int chunk) {
 #pragma unroll
     for (int pr = 0; pr < PH; ++pr) {
       const int h = h0 - 3 + pr;
-      const bool ok = wok && h >= 0 && h < a.H;
-      const float* src = ok ? xn + ((size_t)h * a.W + w) * C + chunk * CK + q * 4 : xn;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-      v[pr] = ok ? t : ninf;
+      const int hcl = h < 0 ? 0 : h >= a.H ? a.H - 1 : h;
+      v[pr] = *reinterpret_cast<const f32x4*>(xn + ((size_t)hcl * a.W + wcl) * C + chunk * CK + q * 4);
     }
   };
 
@@ -1365,14 +1351,11 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
     {  // all lanes run the row pass (exterior columns on a clamped window, results unused) so
        // the cross-lane reduction below is never inside divergent control flow
       const int pcc = interior ? pc - 3 : 0;
-      float w1r[4][R];
+      float w1r[4][R];   // slot s = squeeze channel s ^ (q & (R-1)), see cam_reduce_scatter
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int rr = 0; rr < R; rr += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(w1c + (q * 4 + e) * R + rr);
-          w1r[e][rr] = t[0]; w1r[e][rr + 1] = t[1]; w1r[e][rr + 2] = t[2]; w1r[e][rr + 3] = t[3];
-        }
+        for (int sl = 0; sl < R; ++sl) w1r[e][sl] = w1c[(q * 4 + e) * R + (sl ^ (q & (R - 1)))];
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
         const float* src = colmax + (r * PW + pcc) * CK + q * 4;
@@ -1391,7 +1374,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
           for (int e = 1; e < 4; ++e) t = fmaf(m[e], w1r[e][rr], t);
           p[rr] = t;
         }
-        sp[r] += cam_reduce_scatter<R, QP>(p, q);
+        sp[r] += cam_reduce_scatter<R>(p);
       }
     }
     __syncthreads();
@@ -1445,7 +1428,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
           for (int e = 0; e < 4; ++e)  // sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, ~1 ulp each)
             o[e] = xs_reg[chunk][r][e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * z[e]));
           if constexpr (SQ > 0) {
-            if (h >= a.H) o = (f32x4){0.f, 0.f, 0.f, 0.f};   // (rows below the image: -inf * gate; never stored)
+            if (h >= a.H) o = (f32x4){0.f, 0.f, 0.f, 0.f};   // (rows below the image hold clamped duplicates; never stored)
             f16x4 hi, lo;
             split4(o, hi, lo);
             vmax = absmax4(vmax, o);
