@@ -12,6 +12,9 @@
 
 #include "../../include/pclseg.h"
 #include "pclseg_graph.h"
+#ifndef PCLSEG_SLOTS
+#define PCLSEG_SLOTS 2
+#endif
 #include "pclseg_kernels.h"
 
 using namespace pclseg;
@@ -48,6 +51,7 @@ struct pclseg_handle {
   // its own activation arena and HIP stream: kernels of different micro-batches overlap on the
   // GPU (a memory-bound kernel of one fills the idle pipes of a latency-bound kernel of another).
   static constexpr int kMaxLanes = 8;
+  static constexpr int kSlotsPerLane = PCLSEG_SLOTS;
   int nlanes = 1;
   float* d_arena_lane[kMaxLanes] = {nullptr};
   uint8_t* d_mask_lane[kMaxLanes] = {nullptr};
@@ -67,7 +71,7 @@ struct pclseg_handle {
     // ev_in: the slot's H2D copies landed; ev_done: its kernels finished; ev_out: its D2H copies finished
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
     bool used = false;
-  } hl[2 * kMaxLanes];            // two slots per lane: micro-batch k+1 of a lane uploads while k computes
+  } hl[kSlotsPerLane * kMaxLanes];            // two slots per lane: micro-batch k+1 of a lane uploads while k computes
   bool host_async_pending = false;   // PCLSEG_MEM_HOST_ASYNC calls enqueued since the last pclseg_sync
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // dedicated copy streams (SDMA engines run beside the kernels)
   hipEvent_t ev_copy_tail = nullptr;
@@ -792,7 +796,7 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
 
   bool in_pinned = false, mask_pinned = false;
   int32_t* o_preds = preds; float* o_probs = probs; float* o_logits = logits; uint8_t* o_mask = mask_out;
-  const int nslots = std::min(2 * h->nlanes, nmb);
+  const int nslots = std::min(pclseg_handle::kSlotsPerLane * h->nlanes, nmb);
   if (host) {
     int rc;
     if (!h->s_h2d) {
@@ -854,7 +858,7 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     const size_t P = (size_t)cnt * HW;
     const int lane = mbi % h->nlanes;
     const hipStream_t stream = multi ? h->lane_stream[lane] : h->stream;
-    pclseg_handle::HostLane& L = h->hl[host ? mbi % (2 * h->nlanes) : lane];   // slot s always serves lane s % nlanes
+    pclseg_handle::HostLane& L = h->hl[host ? mbi % (pclseg_handle::kSlotsPerLane * h->nlanes) : lane];   // slot s always serves lane s % nlanes
     float* d_lidar8 = h->d_arena_lane[lane] + g.tensors[g.t_input].offset;
     const float* d_in = input + (size_t)s0 * HW * cin;
     const uint8_t* d_mask_in = mask_in ? mask_in + (size_t)s0 * HW : nullptr;
@@ -1127,7 +1131,7 @@ int pclseg_destroy(pclseg_handle* h) {
     if (h->d_mask_lane[l]) (void)hipFree(h->d_mask_lane[l]);
   }
   if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-  for (int l = 0; l < 2 * pclseg_handle::kMaxLanes; ++l) {
+  for (int l = 0; l < pclseg_handle::kSlotsPerLane * pclseg_handle::kMaxLanes; ++l) {
     pclseg_handle::HostLane& L = h->hl[l];
     void* dev[] = {L.d_in, L.d_maskin, L.d_preds, L.d_probs, L.d_logits};
     for (void* p : dev) if (p) (void)hipFree(p);

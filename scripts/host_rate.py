@@ -35,9 +35,11 @@ for name, mem, src, dst in (("device", E.MEM_DEVICE, scans, preds), ("sync", E.M
   t = time.perf_counter()
   for _ in range(steps):
     eng.forward_raw(src, batch, dst, None, None, None, mem=mem)
+  t_enq = time.perf_counter() - t      # time the calls themselves took (enqueue only, for device / async)
   eng.sync()
   torch.cuda.synchronize(dev)
   res[name] = batch * steps / (time.perf_counter() - t)
+  res[name + "_call_ms"] = 1e3 * t_enq / steps
   assert torch.equal(dst.cpu(), preds.cpu())
-print(" ".join("%s=%.0f" % kv for kv in res.items()), "sync/device=%.3f async/device=%.3f" % (
+print(" ".join("%s=%.4g" % kv for kv in res.items()), "sync/device=%.3f async/device=%.3f" % (
   res["sync"] / res["device"], res["async"] / res["device"]))
