@@ -548,6 +548,12 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     return op.up_fused ? launch_conv_up(op, epi, grid, lds, s, a) : launch_conv_pair(op, epi, grid, lds, s, a);
   }
   if (op.up_fused) return hipErrorInvalidValue;
+  if (op.nw == 8) {   // Darknet's wide layers: 128 px x 128 couts, 8 waves (op_geometry)
+    if (exact || op.kind == OP_HEAD || op.ntw != 2) return hipErrorInvalidValue;
+    if (op.mtw == 4 && op.wn == 4) return launch_conv_epi<4, 2, 4, false, true, false, 8>(epi, grid, lds, s, a);
+    if (op.mtw == 8 && op.wn == 8) return launch_conv_epi<8, 2, 8, false, true, false, 8>(epi, grid, lds, s, a);
+    return hipErrorInvalidValue;
+  }
   if (op.kind == OP_HEAD)
     return exact ? launch_conv_cfg<true, false>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a)
                  : launch_conv_cfg<true, true>(op.mtw, op.ntw, op.wn, epi, grid, lds, s, a);

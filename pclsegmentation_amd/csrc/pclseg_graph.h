@@ -193,6 +193,16 @@ inline void op_geometry(Op* op) {
   op->mtw = (op->wn == 1 && op->nsub == 1 && op->ntw != 1) ? 2 : 4;
   op->nw = 4;
   if (op->pair) pair_geometry(op);
+  // Darknet's wide layers (couts a multiple of 128, single sub-conv, 3x3 and 1x1): 8-wave blocks on the
+  // same 128-pixel tile with 128 or 256 couts per block — the patch is staged once per 128/256 couts
+  // instead of once per 64, and a weight fragment feeds 8 pixel segments instead of 4.  Measured
+  // (Darknet-53 64x2048 / Darknet-21 32x1024 scans/s): 4-wave 334 / 2449, 128 couts 351 / 2578,
+  // 256 couts where they divide 360 / 2657, the 1x1 layers too 364 / 2675.  (tuning aid: 0..3)
+  static const int dn8 = getenv("PCLSEG_DN8") ? atoi(getenv("PCLSEG_DN8")) : 3;
+  if (dn8 && op->kind == OP_CONV && op->nsub == 1 && !op->pair && nct % 8 == 0 && (dn8 >= 3 || !op_is_flat(*op)) && op->sk_in < 0) {
+    op->nw = 8; op->wn = 4; op->ntw = 2; op->mtw = 4;
+    if (dn8 >= 2 && nct % 16 == 0) { op->wn = 8; op->mtw = 8; }   // 128 px x 256 couts
+  }
   static const int geom_only = getenv("PCLSEG_FSQ_GEOM_ONLY") ? atoi(getenv("PCLSEG_FSQ_GEOM_ONLY")) : 0;   // debug
   if (op->fsq_fused || (geom_only && op->pair && (nct == 16 || nct == 12 || nct == 8) && op->res1 < 0)) {   // 8 waves on a 64-pixel tile, all couts of both halves in the block
     op->nw = 8;
