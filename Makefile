@@ -15,6 +15,6 @@ stamps: $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h i
 	$(HIPCC) $(HIPFLAGS) -DPCLSEG_WITH_STAMPS -o pclsegmentation_amd/libpclseg_stamps.so $(CSRC)/pclseg_api.hip
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so
 
 .PHONY: all clean stamps
