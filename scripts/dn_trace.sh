@@ -2,7 +2,7 @@
 # kernel sequence of one Darknet-53 micro-batch (one lane): duration, grid, kernel
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out; rm -rf gpurun_out/dn
-( export PCLSEG_LANES=1; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/dn -- python3 bench.py --workload ${1:-darknet53_64x2048} --steps 2 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1 )
+( export PCLSEG_LANES=1; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/dn -- python3 bench.py --workload ${1:-darknet53_64x2048} --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary > /dev/null 2>&1 )
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/dn/**/*kernel_trace.csv", recursive=True)[0]
