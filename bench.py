@@ -407,8 +407,9 @@ def main():
     out["host_boundary"] = {
       "value": round(pinned_sync, 1), "unit": "scans/s", "frac_of_device_resident": round(pinned_sync / r["scans_per_s"], 3),
       "note": "PCLSEG_MEM_HOST, page-locked host buffers in and out over PCIe, every call waits for its outputs; "
-              "uploads / downloads per micro-batch on dedicated copy streams, double-buffered per lane, overlapped "
-              "with compute; predictions identical to the device-resident run: %s" % same,
+              "per micro-batch a DMA upload that runs ahead of the lane or a copy kernel on the lane, predictions "
+              "written by the head straight into the caller's buffer, overlapped with the other lanes' compute; "
+              "predictions identical to the device-resident run: %s" % same,
       "enqueue_only_calls": {"value": round(pinned, 1),
                              "note": "PCLSEG_MEM_HOST_ASYNC (calls enqueue, one pclseg_sync at the end)"},
       "pageable": {"value": round(pageable, 1), "note": "PCLSEG_MEM_HOST, pageable NumPy buffers through the library's pinned bounce slabs"}}

@@ -158,8 +158,10 @@ int pclseg_sync(pclseg_handle* h);
 
 /* Page-locked host memory for the PCLSEG_MEM_HOST boundary (the reference hands NumPy arrays to
  * Keras, inference.py:71-75).  Buffers from here (or any hipHostMalloc / hipHostRegister /
- * torch pin_memory buffer) are DMA'd directly and overlapped with compute; pageable buffers are
- * accepted too and go through the library's own pinned bounce buffers. */
+ * torch pin_memory buffer) are read and written by the GPU directly (DMA uploads that run ahead of
+ * the kernels, or copy kernels / direct prediction writes over PCIe where a DMA command would stall the
+ * calling thread) and overlapped with compute; pageable buffers are accepted too and go through the
+ * library's own pinned bounce buffers. */
 void* pclseg_host_alloc(size_t bytes);
 int pclseg_host_free(void* p);
 

@@ -70,6 +70,7 @@ struct pclseg_handle {
     void* p_mask = nullptr; size_t p_mask_bytes = 0;
     // ev_in: the slot's H2D copies landed; ev_done: its kernels finished; ev_out: its D2H copies finished
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+    bool out_dma = false;   // the slot's last micro-batch sent results through the D2H stream (ev_out is meaningful)
     bool used = false;
   } hl[kSlotsPerLane * kMaxLanes];            // two slots per lane: micro-batch k+1 of a lane uploads while k computes
   bool host_async_pending = false;   // PCLSEG_MEM_HOST_ASYNC calls enqueued since the last pclseg_sync
@@ -753,14 +754,26 @@ void drain_after_error(pclseg_handle* h) {
   (void)hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t n) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const size_t n16 = aligned ? n >> 4 : 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t; i < n16; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  for (size_t k = (n16 << 4) + t; k < n; k += stride) dst[k] = src[k];   // tail (or everything, if misaligned)
+}
+int zero_copy_mode() {   // bit 0: inputs, bit 1: predictions
+  static const int on = getenv("PCLSEG_ZERO_COPY") ? atoi(getenv("PCLSEG_ZERO_COPY")) : 3;   // tuning aid: 0 = DMA copies
+  return on;
+}
+bool zero_copy_enabled() { return zero_copy_mode() != 0; }
+
 // Host-boundary staging of one lane (PCLSEG_MEM_HOST).  Device slabs hold one micro-batch; the
 // pinned bounce slab is only used when the caller's input is pageable memory.
 int ensure_host_lane(pclseg_handle* h, int l, size_t in_bytes, size_t px, int NC, bool want_probs, bool want_logits) {
   pclseg_handle::HostLane& L = h->hl[l];
   int rc;
-  if ((rc = ensure(h, (void**)&L.d_in, &L.in_bytes, in_bytes))) return rc;
+  (void)in_bytes;   // (the input and prediction slabs are allocated in sweep(), only where a micro-batch needs them)
   if ((rc = ensure(h, (void**)&L.d_maskin, &L.maskin_bytes, px))) return rc;
-  if ((rc = ensure(h, (void**)&L.d_preds, &L.preds_bytes, px * sizeof(int32_t)))) return rc;
   if (want_probs && (rc = ensure(h, (void**)&L.d_probs, &L.probs_bytes, px * NC * sizeof(float)))) return rc;
   if (want_logits && (rc = ensure(h, (void**)&L.d_logits, &L.logits_bytes, px * NC * sizeof(float)))) return rc;
   return PCLSEG_OK;
@@ -851,6 +864,10 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     }
   }
 
+  const bool need_dma_out = probs != nullptr || logits != nullptr || mask_out != nullptr;
+  // A kernel that reads over PCIe is bound by the link (≈ 50 GB/s), not by the GPU: it gets one small
+  // block per CU, so it leaves the wave slots to the other lanes' kernels while it waits
+  static const unsigned zc_blocks = getenv("PCLSEG_ZC_BLOCKS") ? (unsigned)atoi(getenv("PCLSEG_ZC_BLOCKS")) : 16u;
   NormArgs na;
   for (int i = 0; i < 5; ++i) { na.mean[i] = g.desc.mean[i]; na.std[i] = g.desc.std[i]; }
   if (multi && !host) {  // lanes start after everything already queued on the caller's stream (device inputs);
@@ -872,25 +889,61 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     float* d_probs = probs ? probs + (size_t)s0 * HW * NC : nullptr;
     float* d_logits = logits ? logits + (size_t)s0 * HW * NC : nullptr;
     uint8_t* d_mask_out = mask_out ? mask_out + (size_t)s0 * HW : nullptr;
+    bool zc_in = false, zc_preds = false;   // this micro-batch's input / predictions cross PCIe inside kernels
     if (host) {
-      // upload on the H2D stream into this micro-batch's slot (two slots per lane, so the upload of the
-      // lane's NEXT micro-batch runs while this one computes)
+      int rc0;
       const float* src = d_in;
       const uint8_t* msrc = d_mask_in;
-      if (L.used) HIP_TRY(h, hipStreamWaitEvent(h->s_h2d, L.ev_done, 0));   // slot's previous kernels have read it
       if (!in_pinned || !mask_pinned) {
-        if (L.used) HIP_TRY(h, hipEventSynchronize(L.ev_in));   // the bounce slab's previous upload has left it
+        if (L.used) HIP_TRY(h, hipEventSynchronize(L.ev_in));   // the bounce slab's previous reader / upload has left it
         if (!in_pinned) { memcpy(L.p_in, d_in, P * cin * sizeof(float)); src = (const float*)L.p_in; }
         if (!mask_pinned) { memcpy(L.p_mask, d_mask_in, P); msrc = (const uint8_t*)L.p_mask; }
       }
-      HIP_TRY(h, hipMemcpyAsync(L.d_in, src, P * cin * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
-      if (!raw) HIP_TRY(h, hipMemcpyAsync(L.d_maskin, msrc, P, hipMemcpyHostToDevice, h->s_h2d));
-      HIP_TRY(h, hipEventRecord(L.ev_in, h->s_h2d));
-      HIP_TRY(h, hipStreamWaitEvent(stream, L.ev_in, 0));
-      if (L.used) HIP_TRY(h, hipStreamWaitEvent(stream, L.ev_out, 0));      // slot's previous results have left
+      // With ROCm 7.2 a hipMemcpyAsync queued behind an UNSATISFIED cross-stream event wait blocks the calling
+      // thread until the dependency resolves (measured in steady state: 350 us per upload, 200 us per
+      // download), which starves the other lanes: mean kernels in flight 1.2 instead of 2.4.  Page-locked
+      // host memory is mapped into the GPU's address space, so wherever a DMA command would block, a kernel
+      // on the lane's own stream moves the bytes instead: a small coalesced copy kernel brings the scans in
+      // (ordered by the lane itself: no event), and the head writes the int32 predictions straight into the
+      // caller's buffer.  An upload whose slot is already free still goes through the DMA engine (it then
+      // runs ahead of the lane, beside the kernels).  Optional float outputs (probs / logits / mask) always
+      // leave through the DMA stream.
+      void *zin = nullptr, *zmask = nullptr, *zpreds = nullptr;
+      const int zmode = zero_copy_mode();
+      const bool slot_busy = L.used && hipEventQuery(L.ev_done) != hipSuccess;
+      (void)hipGetLastError();
+      zc_in = (zmode & 1) && (host_async || slot_busy) &&
+              hipHostGetDevicePointer(&zin, const_cast<float*>(src), 0) == hipSuccess &&
+              (raw || hipHostGetDevicePointer(&zmask, const_cast<uint8_t*>(msrc), 0) == hipSuccess);
+      zc_preds = (zmode & 2) && hipHostGetDevicePointer(&zpreds, o_preds + (size_t)s0 * HW, 0) == hipSuccess;
+      (void)hipGetLastError();
+      if ((rc0 = ensure(h, (void**)&L.d_in, &L.in_bytes, (size_t)mb_max * HW * cin * sizeof(float)))) return rc0;
+      if (!zc_preds && (rc0 = ensure(h, (void**)&L.d_preds, &L.preds_bytes, (size_t)mb_max * HW * sizeof(int32_t)))) return rc0;
+      if (zc_in) {
+        // one small block per few CUs: the copy is bound by the link (~50 GB/s), and a large grid would
+        // hold every wave slot of the chip while it waits (16 blocks: 93 % of the device-resident rate for
+        // enqueue-only calls, 256 blocks: 83 %).  16 bytes per lane, fully coalesced — the normalise kernel's
+        // own 20-byte-stride reads would cross PCIe as small partial requests at a quarter of the link rate.
+        hipLaunchKernelGGL(copy_bytes_kernel, dim3(zc_blocks), dim3(256), 0, stream, (const uint8_t*)zin, (uint8_t*)L.d_in, P * cin * sizeof(float));
+        HIP_TRY(h, hipGetLastError());
+        if (!raw) {
+          hipLaunchKernelGGL(copy_bytes_kernel, dim3(zc_blocks), dim3(256), 0, stream, (const uint8_t*)zmask, L.d_maskin, P);
+          HIP_TRY(h, hipGetLastError());
+        }
+        if (!in_pinned || !mask_pinned) HIP_TRY(h, hipEventRecord(L.ev_in, stream));   // the bounce slab has been read
+      } else {
+        // upload on the H2D stream into this micro-batch's slot (two slots per lane, so the upload of the
+        // lane's NEXT micro-batch runs while this one computes)
+        if (L.used) HIP_TRY(h, hipStreamWaitEvent(h->s_h2d, L.ev_done, 0));   // slot's previous kernels have read it
+        HIP_TRY(h, hipMemcpyAsync(L.d_in, src, P * cin * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
+        if (!raw) HIP_TRY(h, hipMemcpyAsync(L.d_maskin, msrc, P, hipMemcpyHostToDevice, h->s_h2d));
+        HIP_TRY(h, hipEventRecord(L.ev_in, h->s_h2d));
+        HIP_TRY(h, hipStreamWaitEvent(stream, L.ev_in, 0));
+      }
+      if (L.used && L.out_dma) HIP_TRY(h, hipStreamWaitEvent(stream, L.ev_out, 0));   // slot's previous results have left
       d_in = (const float*)L.d_in;
       d_mask_in = L.d_maskin;
-      d_preds = L.d_preds;
+      d_preds = zc_preds ? (int32_t*)zpreds : L.d_preds;
       d_probs = probs ? L.d_probs : nullptr;
       d_logits = logits ? L.d_logits : nullptr;
       d_mask_out = raw ? L.d_maskin : nullptr;   // raw mode: the slot's own mask slab (copied out below)
@@ -910,13 +963,16 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     if (rc) return rc;
     if (host) {   // results leave on the D2H stream once the slot's kernels are done
       HIP_TRY(h, hipEventRecord(L.ev_done, stream));
+      L.out_dma = !zc_preds || need_dma_out;
+      L.used = true;
+    }
+    if (host && L.out_dma) {
       HIP_TRY(h, hipStreamWaitEvent(h->s_d2h, L.ev_done, 0));
-      HIP_TRY(h, hipMemcpyAsync(o_preds + (size_t)s0 * HW, d_preds, P * sizeof(int32_t), hipMemcpyDeviceToHost, h->s_d2h));
+      if (!zc_preds) HIP_TRY(h, hipMemcpyAsync(o_preds + (size_t)s0 * HW, d_preds, P * sizeof(int32_t), hipMemcpyDeviceToHost, h->s_d2h));
       if (probs) HIP_TRY(h, hipMemcpyAsync(o_probs + (size_t)s0 * HW * NC, d_probs, P * NC * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
       if (logits) HIP_TRY(h, hipMemcpyAsync(o_logits + (size_t)s0 * HW * NC, d_logits, P * NC * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
       if (mask_out) HIP_TRY(h, hipMemcpyAsync(o_mask + (size_t)s0 * HW, mask_mb, P, hipMemcpyDeviceToHost, h->s_d2h));
       HIP_TRY(h, hipEventRecord(L.ev_out, h->s_d2h));
-      L.used = true;
     }
     h->last_count = cnt;
     h->last_exact = exact;

@@ -348,9 +348,10 @@ def test_split_f16_range_guard_and_exact_fallback(cuda):
 
 
 def test_host_boundary_pinned_and_pageable_agree_with_device(cuda):
-  """PCLSEG_MEM_HOST with page-locked buffers (direct DMA per micro-batch on the lane streams), with
-  pageable buffers (pinned bounce slabs) and PCLSEG_MEM_DEVICE give bit-identical outputs, for a batch
-  that spans several micro-batches per lane and has a ragged tail."""
+  """PCLSEG_MEM_HOST with page-locked buffers (DMA uploads where a slot is free, copy kernels and direct
+  prediction writes over PCIe where a DMA command would block), with pageable buffers (pinned bounce
+  slabs) and PCLSEG_MEM_DEVICE give bit-identical outputs, for a batch that spans several micro-batches
+  per lane and has a ragged tail."""
   import torch
   mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
   model.init_weights(4321)
@@ -401,6 +402,18 @@ def test_host_boundary_pinned_and_pageable_agree_with_device(cuda):
     h_m.copy_(torch.from_numpy(omask.astype(np.uint8)))
     eng.forward(h_lidar, h_m, n, h_preds, None, h_logits, mem=E.MEM_HOST)
     assert np.array_equal(h_preds.numpy(), want_p) and np.array_equal(h_logits.numpy(), want_l)
+    if pinned:
+      # predictions only, enqueue-only: no DMA command at all — a copy kernel on each lane reads the scans
+      # (and, for the reference-shaped entry, the mask) over PCIe and the head writes the class IDs straight
+      # into the caller's buffer; three calls back to back reuse every slot
+      h_preds.zero_(); h_preds2.zero_()
+      h_preds3 = mk(n, h, w, dtype=torch.int32)
+      eng.forward_raw(h_raw, n, h_preds, None, None, None, mem=E.MEM_HOST_ASYNC)
+      eng.forward(h_lidar, h_m, n, h_preds2, None, None, mem=E.MEM_HOST_ASYNC)
+      eng.forward_raw(h_raw, n, h_preds3, None, None, None, mem=E.MEM_HOST_ASYNC)
+      eng.sync()
+      for pp in (h_preds, h_preds2, h_preds3):
+        assert np.array_equal(pp.numpy(), want_p)
   model.micro_batch = 0
   model._drop_engines()
 
