@@ -6,8 +6,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pclseg.h"
@@ -767,6 +772,57 @@ int zero_copy_mode() {   // bit 0: inputs, bit 1: predictions
 }
 bool zero_copy_enabled() { return zero_copy_mode() != 0; }
 
+// Pageable caller buffers cross a pinned bounce slab; one CPU thread copies ~10 GB/s, which at 3 MB per
+// scan caps the boundary below the GPU's rate.  Large copies are therefore split over a few helper threads
+// (process-wide, created on first use, parked on a condition variable in between).
+class CopyPool {
+ public:
+  static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }   // (never destroyed: workers are detached)
+  void copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < ((size_t)1 << 20) || nworkers_ == 0 || getpid() != pid_) { memcpy(dst, src, bytes); return; }   // (a forked child has no workers)
+    std::lock_guard<std::mutex> one_call(call_m_);
+    const int parts = nworkers_ + 1;
+    const size_t chunk = ((bytes / parts) + 4095) & ~(size_t)4095;
+    std::unique_lock<std::mutex> lk(m_);
+    dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes; chunk_ = chunk;
+    next_ = 1; pending_ = nworkers_; ++gen_;
+    lk.unlock();
+    cv_.notify_all();
+    memcpy(dst, src, std::min(chunk, bytes));            // the caller takes part 0
+    lk.lock();
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+ private:
+  CopyPool() {
+    static const int n = getenv("PCLSEG_COPY_THREADS") ? atoi(getenv("PCLSEG_COPY_THREADS")) : 4;   // tuning aid: 1 = caller only
+    nworkers_ = std::max(0, std::min(n, 16) - 1);
+    pid_ = getpid();
+    for (int i = 0; i < nworkers_; ++i) std::thread([this] { run(); }).detach();
+  }
+  void run() {
+    unsigned long seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      cv_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      const int part = next_++;
+      const size_t off = (size_t)part * chunk_;
+      char* d = dst_; const char* s = src_; const size_t total = bytes_, chunk = chunk_;
+      lk.unlock();
+      if (off < total) memcpy(d + off, s + off, std::min(chunk, total - off));
+      lk.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::mutex m_, call_m_;
+  pid_t pid_ = 0;
+  std::condition_variable cv_, done_;
+  char* dst_ = nullptr; const char* src_ = nullptr;
+  size_t bytes_ = 0, chunk_ = 0;
+  int next_ = 0, pending_ = 0, nworkers_ = 0;
+  unsigned long gen_ = 0;
+};
+
 // Host-boundary staging of one lane (PCLSEG_MEM_HOST).  Device slabs hold one micro-batch; the
 // pinned bounce slab is only used when the caller's input is pageable memory.
 int ensure_host_lane(pclseg_handle* h, int l, size_t in_bytes, size_t px, int NC, bool want_probs, bool want_logits) {
@@ -896,7 +952,7 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
       const uint8_t* msrc = d_mask_in;
       if (!in_pinned || !mask_pinned) {
         if (L.used) HIP_TRY(h, hipEventSynchronize(L.ev_in));   // the bounce slab's previous reader / upload has left it
-        if (!in_pinned) { memcpy(L.p_in, d_in, P * cin * sizeof(float)); src = (const float*)L.p_in; }
+        if (!in_pinned) { CopyPool::get().copy(L.p_in, d_in, P * cin * sizeof(float)); src = (const float*)L.p_in; }
         if (!mask_pinned) { memcpy(L.p_mask, d_mask_in, P); msrc = (const uint8_t*)L.p_mask; }
       }
       // With ROCm 7.2 a hipMemcpyAsync queued behind an UNSATISFIED cross-stream event wait blocks the calling
@@ -987,9 +1043,9 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
     if (host_async) return PCLSEG_OK;   // pclseg_sync waits (and reports the range guard)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->host_async_pending = false;
-    if (o_preds != preds) memcpy(preds, o_preds, (size_t)n * HW * sizeof(int32_t));
-    if (probs && o_probs != probs) memcpy(probs, o_probs, (size_t)n * HW * NC * sizeof(float));
-    if (logits && o_logits != logits) memcpy(logits, o_logits, (size_t)n * HW * NC * sizeof(float));
+    if (o_preds != preds) CopyPool::get().copy(preds, o_preds, (size_t)n * HW * sizeof(int32_t));
+    if (probs && o_probs != probs) CopyPool::get().copy(probs, o_probs, (size_t)n * HW * NC * sizeof(float));
+    if (logits && o_logits != logits) CopyPool::get().copy(logits, o_logits, (size_t)n * HW * NC * sizeof(float));
     if (mask_out && o_mask != mask_out) memcpy(mask_out, o_mask, (size_t)n * HW);
   }
   return PCLSEG_OK;

@@ -5,6 +5,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -26,8 +27,9 @@ h_scans = torch.empty((batch, h, w, 5), dtype=torch.float32).pin_memory()
 h_scans.copy_(scans.cpu())
 h_preds = torch.empty((batch, h, w), dtype=torch.int32).pin_memory()
 res = {}
+p_scans, p_preds = h_scans.numpy().copy(), np.empty((batch, h, w), np.int32)   # pageable
 for name, mem, src, dst in (("device", E.MEM_DEVICE, scans, preds), ("sync", E.MEM_HOST, h_scans, h_preds),
-                            ("async", E.MEM_HOST_ASYNC, h_scans, h_preds)):
+                            ("async", E.MEM_HOST_ASYNC, h_scans, h_preds), ("pageable", E.MEM_HOST, p_scans, p_preds)):
   for _ in range(5):
     eng.forward_raw(src, batch, dst, None, None, None, mem=mem)
   eng.sync()
@@ -40,6 +42,6 @@ for name, mem, src, dst in (("device", E.MEM_DEVICE, scans, preds), ("sync", E.M
   torch.cuda.synchronize(dev)
   res[name] = batch * steps / (time.perf_counter() - t)
   res[name + "_call_ms"] = 1e3 * t_enq / steps
-  assert torch.equal(dst.cpu(), preds.cpu())
-print(" ".join("%s=%.4g" % kv for kv in res.items()), "sync/device=%.3f async/device=%.3f" % (
-  res["sync"] / res["device"], res["async"] / res["device"]))
+  assert np.array_equal(dst if isinstance(dst, np.ndarray) else dst.cpu().numpy(), preds.cpu().numpy())
+print(" ".join("%s=%.4g" % kv for kv in res.items()), "sync/device=%.3f async/device=%.3f pageable/device=%.3f" % (
+  res["sync"] / res["device"], res["async"] / res["device"], res["pageable"] / res["device"]))
