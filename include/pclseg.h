@@ -79,8 +79,13 @@ typedef enum pclseg_mem {
 /* Arithmetic of the convolutions.  Activations, accumulation and all outputs are float32 in
  * both modes.
  *   PCLSEG_MATH_F16X3: each float32 operand v is split hi = f16(v), lo = f16(v - hi) and a
- *     product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (22-bit operands; logits
- *     within ~1e-5 of the float64 oracle).  Default.  Requires |activation| < 65504: every kernel that
+ *     product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16.  The pair carries 22 significant
+ *     bits while lo is a normal half, i.e. for |v| >= 2^-3; below that the ABSOLUTE error is 2^-25.
+ *     Weights are therefore pre-scaled per output channel by a power of two (largest |w| of the
+ *     channel -> [2^12, 2^13), undone exactly in the float32 epilogue), so every weight down to 2^-15
+ *     of its channel's maximum keeps 22 bits; activations are split as they are (O(1) values after
+ *     BatchNorm: absolute error 2^-25 where |v| < 1/8).  Measured: logits within ~1e-5 of the float64
+ *     oracle on all three networks (bench.py `parity_check`).  Default.  Requires |activation| < 65504: every kernel that
  *     splits a value checks it, a violation sets a sticky flag on the device and the call that
  *     observes it (a PCLSEG_MEM_HOST forward, or pclseg_sync after PCLSEG_MEM_DEVICE forwards)
  *     returns PCLSEG_ERR_RANGE — or repairs the call, see PCLSEG_FLAG_RANGE_FALLBACK.
@@ -222,6 +227,15 @@ int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int st
 int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int cin,
                    const float* kernel, const float* bias, int num_class, int none_index,
                    int32_t* preds, float* probs, float* logits, int math);
+
+/* CPU only (no GPU needed): what the split-f16 matrix-core path multiplies by.  Packs a Keras
+ * Conv2D kernel (kh,kw,Cin,Cout; 1x1 or 3x3) exactly as pclseg_finalize does in PCLSEG_MATH_F16X3 mode —
+ * per output channel a power-of-two scale 2^k that puts the channel's largest |w| into [2^12, 2^13),
+ * then hi = f16(w 2^k), lo = f16(w 2^k - hi) — and writes, in the same Keras layout, the value the
+ * fragments represent: recon = (hi + lo) 2^-k (float64, exact).  exponents (optional, [Cout]) receives k.
+ * Reference arithmetic this stands in for: TensorFlow float32 Conv2D (requirements.txt:1). */
+int pclseg_op_split_f16_roundtrip(const float* kernel, int kh, int kw, int cin, int cout, double* recon,
+                                  int32_t* exponents);
 
 /* Evaluation metrics (the row after the forward pass: eval.py:41-58, utils/util.py:64-79,
  * tf.metrics.MeanIoU as used in nets/SegmentationNetwork.py:52).  Accumulates the confusion

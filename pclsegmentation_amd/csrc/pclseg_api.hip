@@ -91,6 +91,7 @@ struct pclseg_handle {
   unsigned* d_range = nullptr;
   unsigned* h_range = nullptr;   // pinned host mirror
   bool fallback = false;         // PCLSEG_FLAG_RANGE_FALLBACK: both weight sets resident
+  bool force_exact = false;      // fallback handle whose folded weights cannot be split (non-finite): every sweep is exact
   struct LastCall {              // what pclseg_sync re-runs in exact mode when the guard fired
     bool valid = false;
     const float* input = nullptr; bool raw = false; const uint8_t* mask_in = nullptr; int n = 0;
@@ -160,8 +161,36 @@ inline double folded_w(const Op& op, const SubOp& su, const FoldIn& f, const std
   return k * scale[co];
 }
 
+// bias block of a sub-op: [nctp*16] folded biases, then [nctp*16] inverse weight scales (1 until a
+// split-f16 packer overwrites them; the exact-f32 kernels never read them)
 void pack_bias(const SubOp& su, const std::vector<double>& shift, float* bdst) {
   for (int i = 0; i < su.nctp * 16; ++i) bdst[i] = i < su.cout ? (float)shift[i] : 0.0f;
+  for (int i = 0; i < su.nctp * 16; ++i) bdst[su.nctp * 16 + i] = 1.0f;
+}
+
+// ---- split-f16 weights: per-output-channel power-of-two pre-scale ----------------------------
+// w = hi + lo with hi = f16(w), lo = f16(w - hi) carries 22 significant bits only while lo is a NORMAL
+// half: |lo| <= 2^-11 |w| drops below 2^-14 (subnormal, absolute step 2^-24) as soon as |w| < 2^-3 —
+// which is every weight of a trained or He-initialised layer with a large fan-in.  Each output
+// channel's folded weights are therefore multiplied by 2^k, k chosen so that the channel's largest
+// magnitude lands in [2^12, 2^13), before the split; the float32 epilogue multiplies the accumulator
+// by 2^-k (one fmaf with the bias: exact, free).  Elements down to 2^-15 of the channel maximum keep
+// 22 bits; below that the ABSOLUTE error is 2^-25, i.e. 2^-37 of the channel's largest weight.
+constexpr int kScaleTarget = 12;   // channel max -> [2^12, 2^13): hi <= 8192, far from the f16 limit
+struct ScaleStat { bool nonfinite = false; };
+int scale_exponent(double maxabs) {
+  if (!(maxabs > 0.0) || !std::isfinite(maxabs)) return 0;
+  int e;
+  (void)std::frexp(maxabs, &e);                   // maxabs = m * 2^e, m in [0.5, 1)  ->  in [2^(e-1), 2^e)
+  const int k = kScaleTarget + 1 - e;             // maxabs * 2^k in [2^12, 2^13)
+  return std::max(-100, std::min(100, k));        // keeps 2^-k (and 2^k) normal float32 numbers
+}
+inline void split_store(double w, int k, _Float16* hi_dst, _Float16* lo_dst, ScaleStat* st) {
+  const float ws = (float)std::ldexp(w, k);
+  if (st && !std::isfinite(ws)) st->nonfinite = true;
+  const _Float16 hi = (_Float16)ws;
+  *hi_dst = hi;
+  *lo_dst = (_Float16)(ws - (float)hi);
 }
 
 // exact mode: w32[((t*nc16 + c16)*nctp + ct)*256 + lane*4 + j]
@@ -181,10 +210,24 @@ void pack_w32(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 
 // split-f16 mode: per LDS chunk, K-step s and 16-cout tile ct one 2-KiB block [hi|lo][lane][8];
 // lane group g = lane>>4 of step s owns the (tap, 8-channel group) pair kidx = 4s + g.
-void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<double>& scale, _Float16* dst) {
+// `inv` = the sub-op's inverse-scale block (bias block + nctp*16), see cout scaling above.
+void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<double>& scale, _Float16* dst,
+              float* inv, ScaleStat* st = nullptr) {
   const int taps = su.nkh * su.nkw;
   const int cin8 = (op.cin_t + 7) / 8, ck8_full = op.ck16 / 8;
   const int steps_full = f16_steps_full(op, su), nchunks = f16_chunks(op);
+  std::vector<int> kexp((size_t)su.nctp * 16, 0);
+  for (int co = 0; co < su.cout; ++co) {
+    double m = 0.0;
+    for (int t = 0; t < taps; ++t)
+      for (int ci = 0; ci < op.cin_k; ++ci) {
+        const double w = std::fabs(folded_w(op, su, f, scale, t, ci, co));
+        if (!(w <= m)) m = w;   // (NaN propagates into m)
+      }
+    if (st && !std::isfinite(m)) st->nonfinite = true;
+    kexp[co] = scale_exponent(m);
+  }
+  for (int i = 0; i < su.nctp * 16; ++i) inv[i] = (float)std::ldexp(1.0, -kexp[i]);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int ck8 = std::min(ck8_full, cin8 - chunk * ck8_full);
     const int nk = taps * ck8;
@@ -193,15 +236,14 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
         _Float16* blk = dst + ((size_t)(chunk * steps_full + s) * su.nctp + ct) * 1024;
         for (int lane = 0; lane < 64; ++lane) {
           const int kidx = 4 * s + (lane >> 4);
+          const int co = ct * 16 + (lane & 15);
           for (int j = 0; j < 8; ++j) {
-            float w = 0.0f;
+            double w = 0.0;
             if (kidx < nk) {
               const int tap = kidx / ck8, c8 = kidx % ck8;
-              w = (float)folded_w(op, su, f, scale, tap, (chunk * ck8_full + c8) * 8 + j, ct * 16 + (lane & 15));
+              w = folded_w(op, su, f, scale, tap, (chunk * ck8_full + c8) * 8 + j, co);
             }
-            const _Float16 hi = (_Float16)w;
-            blk[lane * 8 + j] = hi;
-            blk[512 + lane * 8 + j] = (_Float16)(w - (float)hi);
+            split_store(w, kexp[co], &blk[lane * 8 + j], &blk[512 + lane * 8 + j], st);
           }
         }
       }
@@ -212,29 +254,40 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 // lane (p, g) of the wave that owns cout group cg holds, per pixel, channels 4g..4g+3 of its tiles
 // 2st and 2st+1: k-slot (g, j) of partial-GEMM step st is channel
 //   c = co_off(half) + (cg*ntw + 2st + (j >> 2))*16 + 4g + (j & 3)      (zero if that tile does not exist).
-// A-fragment lane (r = lane & 15, g = lane >> 4), element j = BN-folded squeeze weight W[c][16qt + r].
-void pack_fsq(const Op& op, const FoldIn& f, const std::vector<double>& scale, _Float16* dst) {
+// A-fragment lane (r = lane & 15, g = lane >> 4), element j = BN-folded squeeze weight W[c][16qt + r],
+// scaled per squeeze channel q like every split-f16 weight (`inv`: the squeeze's inverse-scale block).
+void pack_fsq(const Op& op, const FoldIn& f, const std::vector<double>& scale, _Float16* dst, float* inv,
+              ScaleStat* st = nullptr) {
   const SubOp& sq = op.fsq;
   const int ncg = op.sub[0].nctp / op.ntw, ns = (op.ntw + 1) / 2, nq = sq.nctp;
   const int cx = op.sub[0].cout + op.sub[1].cout;   // channels of the (never materialised) pair output
+  std::vector<int> kexp((size_t)nq * 16, 0);
+  for (int q = 0; q < sq.cout; ++q) {
+    double m = 0.0;
+    for (int c = 0; c < cx; ++c) {
+      const double w = std::fabs((double)f.kernel[(size_t)c * sq.cout + q] * scale[q]);
+      if (!(w <= m)) m = w;
+    }
+    if (st && !std::isfinite(m)) st->nonfinite = true;
+    kexp[q] = scale_exponent(m);
+  }
+  for (int i = 0; i < nq * 16; ++i) inv[i] = (float)std::ldexp(1.0, -kexp[i]);
   for (int half = 0; half < 2; ++half)
     for (int cg = 0; cg < ncg; ++cg)
-      for (int st = 0; st < ns; ++st)
+      for (int st_ = 0; st_ < ns; ++st_)
         for (int qt = 0; qt < nq; ++qt) {
-          _Float16* blk = dst + ((((size_t)half * ncg + cg) * ns + st) * nq + qt) * 1024;
+          _Float16* blk = dst + ((((size_t)half * ncg + cg) * ns + st_) * nq + qt) * 1024;
           for (int lane = 0; lane < 64; ++lane) {
             const int r = lane & 15, gg = lane >> 4, q = qt * 16 + r;
             for (int j = 0; j < 8; ++j) {
-              const int nn = 2 * st + (j >> 2);
+              const int nn = 2 * st_ + (j >> 2);
               const int cl = (cg * op.ntw + nn) * 16 + 4 * gg + (j & 3);   // channel within the half
-              float w = 0.0f;
+              double w = 0.0;
               if (nn < op.ntw && cl < op.sub[half].cout && q < sq.cout) {
                 const int c = op.sub[half].co_off + cl;
-                if (c < cx) w = (float)((double)f.kernel[(size_t)c * sq.cout + q] * scale[q]);
+                if (c < cx) w = (double)f.kernel[(size_t)c * sq.cout + q] * scale[q];
               }
-              const _Float16 hi = (_Float16)w;
-              blk[lane * 8 + j] = hi;
-              blk[512 + lane * 8 + j] = (_Float16)(w - (float)hi);
+              split_store(w, kexp[q], &blk[lane * 8 + j], &blk[512 + lane * 8 + j], st);
             }
           }
         }
@@ -1077,7 +1130,7 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
   if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE && mem != PCLSEG_MEM_HOST_ASYNC)
     return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
   DeviceGuard guard(h->device);
-  int rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, h->exact);
+  int rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, h->exact || h->force_exact);
   if (rc) { drain_after_error(h); return rc; }
   h->last.valid = false;
   if (mem != PCLSEG_MEM_HOST) {   // asynchronous: pclseg_sync reports / repairs a range overflow
@@ -1112,7 +1165,7 @@ int run_single_op(Op* op, const FoldIn* folds, int n, int h, int w, ConvArgs a, 
     SubOp& su = op->sub[i];
     su.w32_off = nw32; nw32 += sub_w32_floats(*op, su);
     su.w16_off = nw16; nw16 += sub_w16_halfs(*op, su);
-    su.b_off = nb; nb += (size_t)su.nctp * 16;
+    su.b_off = nb; nb += (size_t)sub_bias_floats(su);
   }
   std::vector<float> hb(nb), hw32(exact ? nw32 : 0);
   std::vector<_Float16> hw16(exact ? 0 : nw16);
@@ -1122,7 +1175,7 @@ int run_single_op(Op* op, const FoldIn* folds, int n, int h, int w, ConvArgs a, 
     fold_bn(su, folds[i], &scale, &shift);
     pack_bias(su, shift, hb.data() + su.b_off);
     if (exact) pack_w32(*op, su, folds[i], scale, hw32.data() + su.w32_off);
-    else pack_w16(*op, su, folds[i], scale, hw16.data() + su.w16_off);
+    else pack_w16(*op, su, folds[i], scale, hw16.data() + su.w16_off, hb.data() + su.b_off + su.nctp * 16);
   }
   DevBuf dw, db;
   const size_t wbytes = exact ? nw32 * sizeof(float) : nw16 * sizeof(_Float16);
@@ -1318,6 +1371,7 @@ int pclseg_finalize(pclseg_handle* h) {
   std::vector<float> w32(want32 ? (size_t)h->g.packed32_floats : 0, 0.0f);
   std::vector<_Float16> w16(want16 ? (size_t)h->g.packed16_halfs : 0, (_Float16)0.0f);
   std::vector<float> bias((size_t)h->g.packed_bias_floats, 0.0f);
+  ScaleStat stat;   // non-finite folded weights seen by the split-f16 packers
   for (const Op& op : h->g.ops) {
     if (op.kind == OP_POOL) continue;
     if (op.sk_in >= 0) {  // fused skip branch: [8][C] folded 1x1 weights (rows >= Cin zero) + [C] bias
@@ -1353,9 +1407,9 @@ int pclseg_finalize(pclseg_handle* h) {
         Op as_conv;
         as_conv.cin_t = as_conv.cin_k = op.cin_t;
         as_conv.ck16 = 64;
-        pack_w16(as_conv, su, f, scale, w16.data() + su.w16_off);
+        pack_w16(as_conv, su, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
       } else {
-        pack_fsq(op, f, scale, w16.data() + su.w16_off);
+        pack_fsq(op, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
       }
     }
     if (op.up_fused) {
@@ -1369,7 +1423,7 @@ int pclseg_finalize(pclseg_handle* h) {
         std::vector<double> scale, shift;
         fold_bn(su, f, &scale, &shift);
         pack_bias(su, shift, bias.data() + su.b_off);
-        pack_w16(op, su, f, scale, w16.data() + su.w16_off);
+        pack_w16(op, su, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
       }
     }
     for (int i = 0; i < op.nsub; ++i) {
@@ -1405,8 +1459,16 @@ int pclseg_finalize(pclseg_handle* h) {
       fold_bn(su, f, &scale, &shift);
       pack_bias(su, shift, bias.data() + su.b_off);
       if (want32) pack_w32(op, su, f, scale, w32.data() + su.w32_off);
-      if (want16) pack_w16(op, su, f, scale, w16.data() + su.w16_off);
+      if (want16) pack_w16(op, su, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
     }
+  }
+  if (want16 && stat.nonfinite) {
+    // inf / NaN after BatchNorm folding: float32 arithmetic would propagate it, the hi/lo split cannot
+    // (hi = inf, lo = inf - inf = NaN)
+    if (!h->fallback)
+      return fail(h, PCLSEG_ERR_RANGE, "a BatchNorm-folded weight is not finite: the split-f16 fragments cannot carry it; "
+                                       "create the handle with PCLSEG_FLAG_EXACT_F32 or PCLSEG_FLAG_RANGE_FALLBACK");
+    h->force_exact = true;
   }
   DeviceGuard guard(h->device);
   if (want32) HIP_TRY(h, hipMemcpy(h->d_w32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1612,6 +1674,53 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
   a.in = x;
   a.mask = mask; a.preds = preds; a.probs = probs; a.logits = logits; a.none_index = none_index;
   return run_single_op(&op, &f, n, h, w, a, math);
+}
+
+int pclseg_op_split_f16_roundtrip(const float* kernel, int kh, int kw, int cin, int cout, double* recon,
+                                  int32_t* exponents) {
+  if (!kernel || !recon || cin <= 0 || cout <= 0 || !((kh == 1 && kw == 1) || (kh == 3 && kw == 3)))
+    return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_split_f16_roundtrip");
+  if (cin % 4 || cout % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "Cin and Cout must be multiples of 4");
+  Op op;
+  op.kind = OP_CONV;
+  op.cin_t = op.cin_k = cin;
+  op.pkh = kh; op.pkw = kw; op.sw = 1;
+  SubOp& su = op.sub[0];
+  su.cout = cout; su.nkh = kh; su.nkw = kw;
+  op_geometry(&op);
+  FoldIn f;
+  f.kernel = kernel;
+  std::vector<double> scale, shift;
+  fold_bn(su, f, &scale, &shift);
+  std::vector<_Float16> w16((size_t)sub_w16_halfs(op, su));
+  std::vector<float> inv((size_t)su.nctp * 16);
+  ScaleStat st;
+  pack_w16(op, su, f, scale, w16.data(), inv.data(), &st);
+  if (st.nonfinite) return fail(nullptr, PCLSEG_ERR_RANGE, "non-finite weight");
+  // walk the fragments exactly as the kernels address them and undo the scale
+  const int taps = kh * kw, cin8 = (cin + 7) / 8, ck8_full = op.ck16 / 8;
+  const int steps_full = f16_steps_full(op, su), nchunks = f16_chunks(op);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int ck8 = std::min(ck8_full, cin8 - chunk * ck8_full), nk = taps * ck8;
+    for (int s = 0; s < steps_full; ++s)
+      for (int ct = 0; ct < su.nctp; ++ct) {
+        const _Float16* blk = w16.data() + ((size_t)(chunk * steps_full + s) * su.nctp + ct) * 1024;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int kidx = 4 * s + (lane >> 4), co = ct * 16 + (lane & 15);
+          if (kidx >= nk || co >= cout) continue;
+          const int tap = kidx / ck8, c8 = kidx % ck8;
+          for (int j = 0; j < 8; ++j) {
+            const int ci = (chunk * ck8_full + c8) * 8 + j;
+            if (ci >= cin) continue;
+            recon[((size_t)tap * cin + ci) * cout + co] =
+                ((double)(float)blk[lane * 8 + j] + (double)(float)blk[512 + lane * 8 + j]) * (double)inv[co];
+          }
+        }
+      }
+  }
+  if (exponents)
+    for (int co = 0; co < cout; ++co) exponents[co] = -std::ilogb(inv[co]);
+  return PCLSEG_OK;
 }
 
 int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size_t count,

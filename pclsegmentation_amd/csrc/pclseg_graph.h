@@ -239,6 +239,9 @@ inline void op_geometry(Op* op) {
   if (op->pair && op->ck16 < op->cin_t) op->pair = false;   // merged pairs need the patch in one chunk
 }
 
+// A sub-op's block in the bias blob: [nctp*16] folded biases, then [nctp*16] per-output-channel
+// inverse weight scales 2^-k of the split-f16 fragments (pclseg_api.hip: cout_exponents).
+inline int64_t sub_bias_floats(const SubOp& s) { return (int64_t)2 * s.nctp * 16; }
 inline int64_t sub_w32_floats(const Op& op, const SubOp& s) {
   return (int64_t)s.nkh * s.nkw * ((op.cin_t + 15) / 16) * s.nctp * 256;
 }
@@ -858,7 +861,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
         op.fsq.w16_off = g->packed16_halfs;
         g->packed16_halfs += (int64_t)(C / 32) * op.fsq.nctp * 1024;
         op.fsq.b_off = g->packed_bias_floats;
-        g->packed_bias_floats += (int64_t)op.fsq.nctp * 16;
+        g->packed_bias_floats += sub_bias_floats(op.fsq);
       }
       op.sub[0].b_off = g->packed_bias_floats;
       g->packed_bias_floats += (int64_t)C * R + R;
@@ -876,7 +879,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
       op.fsq.w16_off = g->packed16_halfs;
       g->packed16_halfs += fsq_w16_halfs(op);
       op.fsq.b_off = g->packed_bias_floats;
-      g->packed_bias_floats += (int64_t)op.fsq.nctp * 16;
+      g->packed_bias_floats += sub_bias_floats(op.fsq);
     }
     if (op.up_fused) {   // the transposed conv's two parities, packed like any 2-tap sub-conv of this op
       for (int i = 0; i < 2; ++i) {
@@ -885,7 +888,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
         su.w16_off = g->packed16_halfs;
         g->packed16_halfs += sub_w16_halfs(op, su);
         su.b_off = g->packed_bias_floats;
-        g->packed_bias_floats += (int64_t)su.nctp * 16;
+        g->packed_bias_floats += sub_bias_floats(su);
       }
     }
     for (int i = 0; i < op.nsub; ++i) {
@@ -895,7 +898,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
       su.w16_off = g->packed16_halfs;
       g->packed16_halfs += sub_w16_halfs(op, su);
       su.b_off = g->packed_bias_floats;
-      g->packed_bias_floats += (int64_t)su.nctp * 16;
+      g->packed_bias_floats += sub_bias_floats(su);
     }
   }
   plan_workspace(g);

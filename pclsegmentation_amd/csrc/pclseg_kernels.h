@@ -120,6 +120,16 @@ __device__ __forceinline__ void store_quad(float* dst, const f32x4 v, const bool
   else *reinterpret_cast<f32x4*>(dst) = v;
 }
 
+// Accumulator -> pre-activation value.  Split-f16 weights are packed with a per-output-channel scale
+// 2^k (pclseg_api.hip: scale_exponent), so the accumulator holds 2^k times the convolution sum: one fmaf
+// with the channel's 2^-k and its bias undoes it exactly (a power of two never rounds).
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 s, const f32x4 b) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = fmaf(a[e], s[e], b[e]);
+  return r;
+}
+
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
   return fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -265,10 +275,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
     // HERE, not hoisted above the K loop where it would cost registers for its whole duration
     int p = lane & 15, g = lane >> 4;
     asm volatile("" : "+v"(p), "+v"(g));
-    f32x4 bv[NTW];
+    f32x4 bv[NTW], iv[F16X3 ? NTW : 1];   // bias, and (split-f16) the inverse weight scale of each channel
 #pragma unroll
-    for (int nn = 0; nn < NTW; ++nn)
+    for (int nn = 0; nn < NTW; ++nn) {
       bv[nn] = *reinterpret_cast<const f32x4*>(E.bias + (ct0 + nn) * 16 + g * 4);
+      if constexpr (F16X3) iv[nn] = *reinterpret_cast<const f32x4*>(E.bias + (E.nctp + ct0 + nn) * 16 + g * 4);
+    }
+    auto pre = [&](const f32x4 acv, const int nn) -> f32x4 {
+      if constexpr (F16X3) return fma4(acv, iv[nn], bv[nn]); else return acv + bv[nn];
+    };
     if constexpr (!HEAD) {
       // vmcnt retires loads AND stores in issue order, so a residual load issued after a store
       // would wait for that store's acknowledgement: tile after tile, the epilogue would pay a full
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
           if (validm[m] && co < E.Cout) {
-            f32x4 v = act4(ac[m][nn] + bv[nn], E.act);
+            f32x4 v = act4(pre(ac[m][nn], nn), E.act);
             if constexpr (kR1) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
             if constexpr (kR2) if (a.res2) v += r2[m][nn];
             if constexpr (kSk) if (a.skx) {
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int co = nn * 16 + g * 4 + i;
-            const float v = ac[m][nn][i] + bv[nn][i];
+            const float v = pre(ac[m][nn], nn)[i];
             val[nn * 4 + i] = v;
             if (co < NC) {
               if (a.logits && valid) a.logits[pix * NC + co] = v;
@@ -608,7 +623,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       //     during (1)) and stay in registers while it walks the 16-pixel units of that parity, B operands
       //     from the LDS copy (units are dealt to the NSL waves that share a pair when 2*UP < NW).
       constexpr int NCT = UP > 0 ? UP : 1;
-      constexpr int C = 16 * NCT, ck8 = C >> 3, nk = 2 * ck8, nsteps = NCT;   // (host-checked: a.Cin == 16 * UP)
+      constexpr int C = 16 * NCT, ck8 = C >> 3, nsteps = NCT;   // (host-checked: a.Cin == 16 * UP)
       constexpr int NPAIR = 2 * NCT, NSL = NW / NPAIR > 0 ? NW / NPAIR : 1;
       constexpr int SS = 2 * C + kPadF16;               // halfs per source pixel: [hi C | lo C | pad]
       constexpr int UPP = 2 * C / 8;                    // 16-byte units per source pixel (power of two)
@@ -627,7 +642,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           wl[s] = *reinterpret_cast<const f16x8*>(wq + (size_t)s * a.up_nctp * 1024 + 512);
         }
       }
-      const f32x4 ub = *reinterpret_cast<const f32x4*>(a.up_bias + ct * 16 + g * 4);
+      // (each parity's sub-conv has its own [bias | inverse scale] block, pclseg_graph.h: sub_bias_floats)
+      const float* ubp = a.up_bias + (parity * 2 * a.up_nctp + ct) * 16 + g * 4;
+      const f32x4 ub = *reinterpret_cast<const f32x4*>(ubp);
+      const f32x4 ui = *reinterpret_cast<const f32x4*>(ubp + a.up_nctp * 16);
       {
         const _Float16* in16 = reinterpret_cast<const _Float16*>(a.in) + (size_t)n * a.H * a.up_Win * (size_t)(2 * C);
         const int nunits = a.PH * SC * UPP;
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           au = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], xh, au, 0, 0, 0);
         }
         if (lv) {
-          f32x4 v = au + ub;
+          f32x4 v = fma4(au, ui, ub);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
           vmax = absmax4(vmax, v);
@@ -778,10 +796,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           // wave's cout tiles 2st and 2st+1: lane (p, g) contributes k = (g, j): j < 4 -> channel
           // 4g+j of tile 2st, j >= 4 -> channel 4g+j-4 of tile 2st+1 (zero if NTW is odd and it is missing)
           constexpr int NS = (NTW + 1) / 2;
-          f32x4 bv[NTW];
+          f32x4 bv[NTW], iv[NTW];
 #pragma unroll
-          for (int nn = 0; nn < NTW; ++nn)
+          for (int nn = 0; nn < NTW; ++nn) {
             bv[nn] = *reinterpret_cast<const f32x4*>(K.bias + (ct0 + nn) * 16 + g * 4);
+            iv[nn] = *reinterpret_cast<const f32x4*>(K.bias + (K.nctp + ct0 + nn) * 16 + g * 4);
+          }
           const int cg = ct0 / NTW;   // this wave's cout group within the half
 #pragma unroll
           for (int st = 0; st < NS; ++st) {
@@ -814,9 +834,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
             }
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-              f32x4 v0 = act4(acc[m][2 * st] + bv[2 * st], K.act);
+              f32x4 v0 = act4(fma4(acc[m][2 * st], iv[2 * st], bv[2 * st]), K.act);
               const int n1 = 2 * st + 1 < NTW ? 2 * st + 1 : 2 * st;   // (resolved by the unroller)
-              f32x4 v1 = act4(acc[m][n1] + bv[n1], K.act);
+              f32x4 v1 = act4(fma4(acc[m][n1], iv[n1], bv[n1]), K.act);
               if constexpr (kRes) { v0 += rq[m][0]; v1 += rq[m][1]; }
               if (2 * st + 1 >= NTW) v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
               vmax = absmax4(absmax4(vmax, v0), v1);
@@ -856,10 +876,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
         for (int idx = tid; idx < WMc * PXW * QQ; idx += kThreads) {
           const int px = idx / QQ, qq = idx - px * QQ;
           const int wmi = px / PXW, pl = px - wmi * PXW;
-          f32x4 sum = *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4);
+          f32x4 sum = *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN) * PXW + pl) * QS + qq * 4));
 #pragma unroll
-          for (int w = 0; w < WN; ++w)
+          for (int w = 1; w < WN; ++w)
             sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * QS + qq * 4));
+          sum = fma4(sum, *reinterpret_cast<const f32x4*>(a.fsq_bias + Q + qq * 4), *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4));
 #pragma unroll
           for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.0f);
           const int seg = wmi * MTW + (pl >> 4), pp = pl & 15;
@@ -1031,7 +1052,7 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
         const int co = (ct0 + nn) * 16 + g * 4;
         if (pvalid[m] && co < S.Cout) {
           const size_t px = (size_t)(pix0 + m * 16 + p);
-          v = act4(v + *reinterpret_cast<const f32x4*>(S.bias + co), S.act);
+          v = act4(fma4(v, *reinterpret_cast<const f32x4*>(S.bias + S.nctp * 16 + co), *reinterpret_cast<const f32x4*>(S.bias + co)), S.act);
           if constexpr (RES) if (a.res1) {
             const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + px * a.res1_C + S.co_off + co);
             v = a.res1_mul ? v * r : v + r;
@@ -1060,10 +1081,11 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
   for (int nn = 0; nn < NTW; ++nn) {
     const int co = (ct0 + nn) * 16 + g * 4;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(S.bias + co);
+    const f32x4 iv = *reinterpret_cast<const f32x4*>(S.bias + S.nctp * 16 + co);
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
       if (pvalid[m] && co < S.Cout) {
-        f32x4 v = act4(acc[m][nn] + bv, S.act);
+        f32x4 v = act4(fma4(acc[m][nn], iv, bv), S.act);
         if constexpr (RES) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
         store_out((size_t)(pix0 + m * 16 + p), co, v);
       }
@@ -1170,7 +1192,7 @@ __global__ __launch_bounds__(kConvThreads) void pool_squeeze_kernel(const ConvAr
     for (int nn = 0; nn < NTW; ++nn) {
       const int co = nn * 16 + g * 4;
       if (co >= S.Cout) continue;
-      const f32x4 v = act4(acc[nn] + *reinterpret_cast<const f32x4*>(S.bias + co), S.act);
+      const f32x4 v = act4(fma4(acc[nn], *reinterpret_cast<const f32x4*>(S.bias + S.nctp * 16 + co), *reinterpret_cast<const f32x4*>(S.bias + co)), S.act);
       if (a.out_s16) {
         f16x4 hi, lo;
         split4(v, hi, lo);
@@ -1475,7 +1497,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
       for (int nn = 0; nn < SQ; ++nn) {
         const int co = nn * 16 + g * 4;
         if (co >= a.sq_C) continue;
-        f32x4 v = acc[nn] + *reinterpret_cast<const f32x4*>(a.sq_bias + co);
+        f32x4 v = fma4(acc[nn], *reinterpret_cast<const f32x4*>(a.sq_bias + SQ * 16 + co), *reinterpret_cast<const f32x4*>(a.sq_bias + co));
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
         if (a.sq_s16) {

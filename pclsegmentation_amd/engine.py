@@ -34,7 +34,7 @@ EXPORTS = [
   "pclseg_set_stream", "pclseg_sync", "pclseg_host_alloc", "pclseg_host_free", "pclseg_forward", "pclseg_forward_raw",
   "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
   "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
-  "pclseg_op_confusion_matrix", "pclseg_op_project", "pclseg_op_project_ex",
+  "pclseg_op_confusion_matrix", "pclseg_op_project", "pclseg_op_project_ex", "pclseg_op_split_f16_roundtrip",
 ]
 
 
@@ -114,6 +114,7 @@ def load_library():
                                     ctypes.c_float, vp, vp, vp, vp]
   lib.pclseg_op_project_ex.argtypes = [ctypes.POINTER(ProjDesc), vp, i32, ctypes.c_size_t, vp, vp, vp, vp, i32,
                                        vp, vp, vp, vp]
+  lib.pclseg_op_split_f16_roundtrip.argtypes = [f32p, i32, i32, i32, i32, vp, vp]
   for name in EXPORTS:
     fn = getattr(lib, name)
     if name not in ("pclseg_last_error", "pclseg_host_alloc"):
@@ -365,6 +366,17 @@ def op_head(x_dev, mask_dev, n, h, w, cin, kernel, bias, none_index, preds_dev, 
   check(load_library().pclseg_op_head(_ptr(x_dev), _ptr(mask_dev), n, h, w, cin, _ptr(k), _ptr(b),
                                       nc, none_index, _ptr(preds_dev), _ptr(probs_dev),
                                       _ptr(logits_dev), MATH[math]))
+
+
+def op_split_f16_roundtrip(kernel):
+  """CPU only: (recon float64, exponents int32) — the values the split-f16 fragments of a Keras conv
+  kernel (kh,kw,Cin,Cout) represent after the per-output-channel pre-scale, and the exponents k."""
+  k = _host_f32(kernel)
+  kh, kw, cin, cout = k.shape
+  recon = np.zeros(k.shape, np.float64)
+  exps = np.zeros(cout, np.int32)
+  check(load_library().pclseg_op_split_f16_roundtrip(_ptr(k), kh, kw, cin, cout, _ptr(recon), _ptr(exps)))
+  return recon, exps
 
 
 def op_confusion_matrix(labels_dev, preds_dev, count, num_class, cm_dev, stream=0):

@@ -198,3 +198,38 @@ def test_engine_rejects_mistyped_or_short_buffers():
     _checked(t.transpose(0, 2), np.int32, t.numel(), "preds", MEM_HOST)
   with pytest.raises(ValueError):
     _checked(t, np.int32, t.numel(), "preds", MEM_DEVICE)
+
+
+@pytest.mark.parametrize("kh,cin,cout,sigma", [
+  (3, 1024, 64, 0.0147),   # Darknet deep layer: He-scaled weights, fan-in 9*1024
+  (3, 64, 32, 0.059),      # fan-in 576
+  (1, 512, 64, 0.0625),    # a FIRE squeeze
+  (3, 64, 20, 1e-4),       # a trained layer with very small weights
+  (1, 32, 16, 300.0),      # and one with large ones (BatchNorm gamma/sqrt(var) can do that)
+])
+def test_split_f16_weights_keep_22_bits(kh, cin, cout, sigma):
+  """hi = f16(w), lo = f16(w - hi) falls into f16 SUBNORMALS for |w| < 2^-3
+  (p99 relative reconstruction error 8e-5 on sigma = 0.0147 weights).  With the per-output-channel
+  power-of-two pre-scale the fragments the matrix cores multiply by reproduce every weight to
+  2^-22 relative, except those below 2^-15 of their channel's maximum (absolute error 2^-37 of it)."""
+  rng = np.random.default_rng(7)
+  k = (rng.standard_normal((kh, kh, cin, cout)) * sigma).astype(np.float32)
+  k[0, 0, 0, :4] = 0.0                       # exact zeros stay exact
+  recon, exps = E.op_split_f16_roundtrip(k)
+  assert recon.shape == k.shape and np.all(recon[0, 0, 0, :4] == 0.0)
+  kd = k.astype(np.float64)
+  cmax = np.abs(kd).reshape(-1, cout).max(0)
+  scaled = cmax * np.exp2(exps.astype(np.float64))
+  assert np.all((scaled >= 2.0 ** 12) & (scaled < 2.0 ** 13)), "channel maximum must land in [2^12, 2^13)"
+  nz = kd != 0
+  rel = np.abs(recon - kd)[nz] / np.abs(kd)[nz]
+  assert np.percentile(rel, 99) <= 2e-7, np.percentile(rel, 99)
+  big = np.abs(kd) >= cmax * 2.0 ** -15
+  assert np.abs(recon - kd)[big & nz].max() / 1.0 <= np.abs(kd)[big & nz].max() * 2.0 ** -21
+  assert (np.abs(recon - kd) <= np.maximum(np.abs(kd) * 2.0 ** -21, cmax * 2.0 ** -36)).all()
+  # the unscaled split, emulated: this is what round 2 shipped
+  hi = k.astype(np.float16)
+  lo = (k - hi.astype(np.float32)).astype(np.float16)
+  old = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - kd)[nz] / np.abs(kd)[nz]
+  if sigma < 0.02:
+    assert np.percentile(old, 99) > 1e-5      # (documents the defect the scale removes)
