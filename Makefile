@@ -14,7 +14,12 @@ $(LIB): $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h i
 stamps: $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
 	$(HIPCC) $(HIPFLAGS) -DPCLSEG_WITH_STAMPS -o pclsegmentation_amd/libpclseg_stamps.so $(CSRC)/pclseg_api.hip
 
-clean:
-	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so
+# A/B build: the experiment switches of DESIGN.md §9/§10 (PCLSEG_GEOM, PCLSEG_DN8, ...) are read from the
+# environment (PCLSEG_LIB=.../libpclseg_tuning.so); the shipped library carries only their defaults
+tuning: $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
+	$(HIPCC) $(HIPFLAGS) -DPCLSEG_TUNING -o pclsegmentation_amd/libpclseg_tuning.so $(CSRC)/pclseg_api.hip
 
-.PHONY: all clean stamps
+clean:
+	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so pclsegmentation_amd/libpclseg_tuning.so
+
+.PHONY: all clean stamps tuning

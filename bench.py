@@ -87,16 +87,16 @@ def cpu_baseline(model_name, mc, weights, h, w, pvalid, budget_s):
                    % (done, h, w),
          "legs": {"batch1_%dthreads" % cores: {"value": b1, "scans": done_b1},
                   "batch1_1thread": {"value": t1, "scans": done_t1}}}
-  real = os.path.join(ROOT, "tests", "golden", "model_ssv2_real_32x240.npz")
+  real = os.path.join(ROOT, "tests", "golden", "c1_sample_dataset_train_32x240.npz")
   if model_name == "squeezesegv2" and os.path.exists(real):
-    # BASELINE.json configs[0] (C1): SqueezeSegV2 / NC 11 on real scans of the reference's
-    # dataset_samples/sample_dataset (committed as a fixture), the reference's B = 1 loop
+    # BASELINE.json configs[0] (C1): SqueezeSegV2 / NC 11 on the 32 real scans of the reference's
+    # dataset_samples/sample_dataset/train (committed as a fixture), the reference's B = 1 loop
     import pclsegmentation_amd as P
     from pclsegmentation_amd.nets.weights import synthetic_weights
     mc1, m1 = P.load_model_config("squeezesegv2", "squeezesegv2")
     net1 = TorchNet("squeezesegv2", synthetic_weights(m1.weight_spec(), 4321))
     raw1 = np.load(real)["raw"]
-    c1, done_c1 = _cpu_leg(net1, mc1, raw1, cores, 1, 2.0, 64)
+    c1, done_c1 = _cpu_leg(net1, mc1, raw1, cores, 1, 3.0, 32)   # one pass over the 32 real scans at most
     out["legs"]["c1_real_32x240_batch1_%dthreads" % cores] = {"value": c1, "scans": done_c1}
   torch.set_num_threads(cores)
   return out
@@ -202,20 +202,39 @@ def csrc_sha():
   return h.hexdigest()[:16]
 
 
+def visible_gpu_count():
+  """GPUs this process tree may use, WITHOUT touching HIP (the launcher must stay free of any GPU state:
+  its children are the only processes that initialise the device).  KFD topology nodes with SIMDs are GPUs;
+  ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the set."""
+  import glob
+  n = 0
+  for node in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+    try:
+      props = dict(l.split()[:2] for l in open(node).read().splitlines() if len(l.split()) >= 2)
+      n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+      pass
+  for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    v = os.environ.get(var)
+    if v is not None:
+      n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+  return n
+
+
 def self_launch(args):
   """`python bench.py --gpus N` (N > 1) outside torchrun: start N fresh rank processes with
-  torch.distributed.run and relay their exit status.  Nothing in THIS process has touched the GPU
-  (torch.cuda.device_count() does not initialise it), and the children are new processes, not an
-  exec of this one."""
+  torch.distributed.run and relay their exit status.  THIS process never touches the GPU — the device
+  count comes from sysfs and the environment, not from HIP — and the children are new processes, not an
+  exec of this one.  Each rank binds to its device and NUMA-local cores before its first GPU call
+  (pclsegmentation_amd.distributed.bind_rank)."""
   import socket
   import subprocess
-  import torch
   with socket.socket() as so:
     so.bind(("127.0.0.1", 0))
     port = so.getsockname()[1]
   env = dict(os.environ)
   env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-  if torch.cuda.device_count() < args.gpus:
+  if visible_gpu_count() < args.gpus:
     # fewer GPUs than ranks (e.g. a 1-GPU box): ranks share devices, and RCCL cannot put two
     # ranks on one device -> rendezvous / broadcast over gloo.  A functional check, not a scaling run.
     env["PCLSEG_DIST_BACKEND"] = "gloo"
@@ -225,14 +244,17 @@ def self_launch(args):
 
 
 def build_engine(P, D, synthetic_weights, workload, dev_index, dev, rank, micro_batch=0, flags=0, batch=0):
+  """Rank 0 creates the (seeded) weights, folds and packs them once; the packed device blob is
+  broadcast (RCCL over xGMI) and the other ranks import it — pclsegmentation_amd.distributed.broadcast_engine."""
   model_name, config_name, h, w, wl_batch, pvalid, bound = WORKLOADS[workload]
   mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=dev_index,
                                   micro_batch=micro_batch)
-  spec = model.weight_spec()
-  weights = synthetic_weights(spec, 4321) if rank == 0 else None
-  weights = D.broadcast_weights(spec, weights, src=0, device=dev)   # one RCCL broadcast over xGMI
-  model.set_weights(weights)
-  return mc, model, model.engine(h, w, flags), weights, (batch or wl_batch)
+  weights = None
+  if rank == 0:
+    weights = synthetic_weights(model.weight_spec(), 4321)
+    model.set_weights(weights)
+  eng = D.broadcast_engine(model, h, w, flags, src=0, device=dev)
+  return mc, model, eng, weights, (batch or wl_batch)
 
 
 def time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence):
@@ -266,12 +288,79 @@ def roofline_of(bound, scans_per_s_dev, info):
     roof = {"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(mfma_tf / peak, 4), "traffic": None}
   roof["kernel"] = "all kernels of one forward step (HIP events on the engine stream)"
+  roof["scans_per_s_device_clock"] = round(scans_per_s_dev, 2)
   roof["alg_bytes_per_scan"] = alg_bytes
   roof["alg_flops_per_scan"] = alg_flops
   roof["other"] = {"hbm_GBs": round(hbm_gbs, 1), "alg_TFLOPs": round(mfma_tf, 2),
                    "frac_of_f16_mfma_peak_div3": round(mfma_tf / (F16_MFMA_PEAK_TF / 3.0), 4),
                    "frac_of_f32_mfma_peak": round(mfma_tf / F32_MFMA_PEAK_TF, 4)}
   return roof
+
+
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
+
+
+def attach_traffic(roof, workload, scans_per_s_dev, info):
+  """Measured HBM-side bytes per scan (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+  same command, committed under profiles/) — quoted only when the committed figure was measured on
+  exactly these kernel sources — and the PHYSICAL roofline fractions that follow from it: the ALG
+  fraction counts every reference module's input and output, which fusion no longer moves."""
+  if not os.path.exists(TRAFFIC_JSON):
+    return
+  t = json.load(open(TRAFFIC_JSON))
+  w = t.get("workloads", {}).get(workload)
+  if not w:
+    return
+  if t.get("csrc_sha") != csrc_sha():
+    roof["traffic_note"] = ("profiles/r03_traffic.json was measured on csrc sha %s, this build is %s: stale "
+                            "figure withheld" % (t.get("csrc_sha"), csrc_sha()))
+    return
+  roof["traffic"] = int(w["hbm_bytes_per_scan"])
+  roof["traffic_unit"] = ("HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
+                          "profiles/r03_traffic.json, csrc sha %s" % t["csrc_sha"])
+  roof["physical"] = {
+    "hbm_frac": round(w["hbm_bytes_per_scan"] * scans_per_s_dev / (HBM_PEAK_GBS * 1e9), 4),
+    "mfma_frac": round(3 * 2 * info["alg_macs_per_scan"] * scans_per_s_dev / (F16_MFMA_PEAK_TF * 1e12), 4),
+    "note": "hbm_frac = measured traffic x scans/s / 8 TB/s; mfma_frac = 3 f16 products per MAC x ALG_FLOPS x scans/s / 2.5 PFLOP/s"}
+
+
+def parity_check(P, E, synthetic_weights, synthetic_scans, workload, dev, dev_index):
+  """One scan of `workload` at its full size against the float64 oracle (oracle/np_oracle.py), both
+  arithmetic modes, OUTSIDE any timed region: the evidence that the numbers in this line are numbers of
+  a correct forward pass (north_star: class IDs identical where decided, logits within 1e-3)."""
+  import torch
+  from oracle import np_oracle as O      # the checker, never the thing measured
+  model_name, config_name, h, w, _, pvalid, _ = WORKLOADS[workload]
+  mc, model = P.load_model_config(model_name, config_name, height=h, width=w, device=dev_index)
+  model.set_weights(synthetic_weights(model.weight_spec(), 4321))
+  raw = synthetic_scans(1, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid, seed=1234)
+  none_index = mc.CLASSES.index("None")
+  lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  kw = {"num_layers": mc.get("NUM_LAYERS")} if model_name != "squeezesegv2" else {}
+  t0 = time.perf_counter()
+  _, opred, ologits = O.forward(model.arch_name(), model.weights, lidar, omask, none_index, dtype=np.float64, **kw)
+  oracle_s = time.perf_counter() - t0
+  srt = np.sort(ologits[0], -1)
+  decided = (srt[..., -1] - srt[..., -2]) > 2e-3
+  out = {"workload": workload, "scan": "synthetic seed 1234, scan 0, %dx%d" % (h, w),
+         "oracle": "oracle/np_oracle.py float64 (%.1f s)" % oracle_s,
+         "decided_pixels": int(decided.sum()), "pixels": int(decided.size),
+         "max_abs_logit": round(float(np.abs(ologits).max()), 3)}
+  d_raw = torch.from_numpy(raw).to(dev)
+  for key, flags in (("f16x3", 0), ("f32", E.FLAG_EXACT_F32)):
+    eng = model.engine(h, w, flags)
+    preds = torch.empty((1, h, w), dtype=torch.int32, device=dev)
+    logits = torch.empty((1, h, w, mc.NUM_CLASS), dtype=torch.float32, device=dev)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.forward_raw(d_raw, 1, preds, None, logits, None, mem=E.MEM_DEVICE)
+    eng.sync()
+    pr, lg = preds.cpu().numpy()[0], logits.cpu().numpy()[0].astype(np.float64)
+    out["max_abs_logit_err_" + key] = float("%.3g" % np.abs(lg - ologits[0]).max())
+    out["decided_identical_" + key] = bool(np.array_equal(pr[decided], opred[0][decided]))
+    out["masked_are_none_" + key] = bool((pr[~omask[0]] == none_index).all())
+    model._drop_engines()
+  out["decided_identical"] = out["decided_identical_f16x3"] and out["decided_identical_f32"]
+  return out
 
 
 def main():
@@ -281,10 +370,14 @@ def main():
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--workload", default="ssv2_64x2048", choices=sorted(WORKLOADS))
   ap.add_argument("--batch", type=int, default=0, help="scans per GPU per step (0 = workload default)")
+  ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                  help="weak: every GPU runs --batch scans per step (default); strong: --global-batch scans per "
+                       "step are sharded over the GPUs by contiguous ranges (BASELINE configs[3]: 256 over 8)")
+  ap.add_argument("--global-batch", type=int, default=256, help="scans per step over all GPUs with --scaling strong")
   ap.add_argument("--micro-batch", type=int, default=0)
   ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget; 0 disables")
   ap.add_argument("--no-secondary", action="store_true",
-                  help="skip the secondary rows (Darknet workloads, exact-f32, host boundary)")
+                  help="skip the secondary rows (Darknet workloads, exact-f32, host boundary, parity check)")
   ap.add_argument("--aux", action="store_true", help="measure the projection / confusion-matrix rows instead")
   args = ap.parse_args()
   if args.aux:
@@ -292,9 +385,13 @@ def main():
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     raise SystemExit(self_launch(args))
 
-  import torch
+  # (nothing above has touched the GPU; init_process_group pins the rank to its NUMA-local cores first)
   import pclsegmentation_amd as P
   from pclsegmentation_amd import distributed as D
+  rank, local_rank, world = D.env_world()
+  if world > 1:
+    D.bind_rank(local_rank)
+  import torch
   from pclsegmentation_amd import engine as E
   from pclsegmentation_amd.nets.weights import synthetic_weights
   from pclsegmentation_amd.utils.synthetic import synthetic_scans
@@ -320,6 +417,13 @@ def main():
     model_name, config_name, h, w, _, pvalid, bound = WORKLOADS[workload]
     mc, model, eng, weights, batch = build_engine(P, D, synthetic_weights, workload, dev_index, dev, rank,
                                                   args.micro_batch, flags, batch)
+    global_batch = batch * world
+    if args.scaling == "strong":     # fixed total work: this rank's contiguous share of the global batch
+      global_batch = args.global_batch
+      lo, hi = D.shard_range(global_batch, rank, world)
+      batch = hi - lo
+      if batch <= 0:
+        raise SystemExit("--global-batch %d leaves rank %d without scans" % (global_batch, rank))
     eng.set_stream(stream.cuda_stream)
     info = E.plan(eng.desc)
     scans = torch.from_numpy(synthetic_scans(batch, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid,
@@ -333,41 +437,33 @@ def main():
       torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # MAX over ranks
       elapsed, dev_ms = float(t[0]), float(t[1])
     res = {"mc": mc, "model": model, "eng": eng, "weights": weights, "info": info, "batch": batch,
+           "global_batch": global_batch,
            "scans": scans, "preds": preds, "elapsed": elapsed, "dev_ms": dev_ms, "h": h, "w": w,
            "pvalid": pvalid, "bound": bound, "model_name": model_name,
-           "scans_per_s": world * batch * steps / elapsed,
+           "scans_per_s": global_batch * steps / elapsed,
            "dev_scans_per_s": batch * steps / (dev_ms * 1e-3)}
     return res
 
   r = run_workload(args.workload, args.steps, args.warmup, batch=args.batch)
   if rank == 0:
     roof = roofline_of(r["bound"], r["dev_scans_per_s"], r["info"])
-    # measured HBM-side bytes (PMC passes of this same command, committed under profiles/): only
-    # quoted when the committed figure was measured on exactly these kernel sources
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if args.workload == "ssv2_64x2048" and os.path.exists(tpath):
-      t = json.load(open(tpath))
-      if t.get("csrc_sha") == csrc_sha():
-        roof["traffic"] = int(t["hbm_bytes_per_scan"])
-        roof["traffic_unit"] = ("HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
-                                "profiles/r02_traffic.json, csrc sha %s" % t["csrc_sha"])
-      else:
-        roof["traffic_note"] = ("profiles/r02_traffic.json was measured on csrc sha %s, this build is %s: "
-                                "stale figure withheld" % (t.get("csrc_sha"), csrc_sha()))
+    attach_traffic(roof, args.workload, r["dev_scans_per_s"], r["info"])
     mc = r["mc"]
     out = {
       "metric": "LiDAR scans/sec (64x2048) SqueezeSegV2 inference" if args.workload == "ssv2_64x2048"
                 else "LiDAR scans/sec %s inference" % args.workload,
       "value": round(r["scans_per_s"], 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": round(1e3 * r["elapsed"] / args.steps, 3),
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
       "dtype": "f32 (f16x3 products)", "data": "synthetic",
       "config": {"workload": args.workload, "model": r["model_name"], "shape": [r["h"], r["w"]],
-                 "num_class": mc.NUM_CLASS, "batch_per_gpu": r["batch"], "global_batch": r["batch"] * world,
-                 "math": "storage, accumulation and outputs float32; products on split-f16 operands "
-                         "(hi*hi + hi*lo + lo*hi, 22-bit) on v_mfma_f32_16x16x32_f16",
+                 "num_class": mc.NUM_CLASS, "batch_per_gpu": r["batch"], "global_batch": r["global_batch"],
+                 "math": "storage, accumulation and outputs float32; products on split-f16 operands (hi*hi + hi*lo + "
+                         "lo*hi on v_mfma_f32_16x16x32_f16): weights pre-scaled per output channel so every weight "
+                         "keeps 22 bits, activations 22 bits where |v| >= 1/8 and an absolute 2^-25 below; measured "
+                         "logit error in parity_check",
                  "micro_batch": r["info"]["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")),
-                 "parallelism": "batch-sharded x%d" % world},
+                 "parallelism": "batch-sharded x%d (%s scaling, weights folded+packed once and broadcast)" % (world, args.scaling)},
       "roofline": roof,
     }
     if os.environ.get("PCLSEG_DIST_BACKEND") == "gloo" and world > 1:
@@ -422,19 +518,23 @@ def main():
                         "note": "same workload, every product on v_mfma_f32_16x16x4_f32 (bit-exact float32)"}
     x["model"]._drop_engines()
     del x
-    # ---- the other single-GPU configurations of BASELINE.json (parity-tested in tests/, timed here
-    # for a few steps; their bound is the matrix cores)
+    # ---- the other single-GPU configurations of BASELINE.json (parity-tested in tests/, timed here;
+    # their bound is the matrix cores)
     out["secondary"] = []
-    for wl, st, wu in (("darknet53_64x2048", 6, 2), ("darknet21_32x1024", 10, 3)):
+    for wl, st, wu in (("darknet53_64x2048", 20, 4), ("darknet21_32x1024", 20, 4)):
       if wl == args.workload:
         continue
       y = run_workload(wl, st, wu)
+      roof_y = roofline_of(y["bound"], y["dev_scans_per_s"], y["info"])
+      attach_traffic(roof_y, wl, y["dev_scans_per_s"], y["info"])
       out["secondary"].append({
         "workload": wl, "value": round(y["scans_per_s"], 1), "unit": "scans/s", "steps": st, "warmup": wu,
-        "batch": y["batch"], "ms_per_step": round(1e3 * y["elapsed"] / st, 3),
-        "roofline": roofline_of(y["bound"], y["dev_scans_per_s"], y["info"])})
+        "batch": y["batch"], "ms_per_step": round(1e3 * y["elapsed"] / st, 3), "roofline": roof_y})
       y["model"]._drop_engines()
       del y
+    # ---- parity evidence of this very build, outside every timed region
+    out["parity_check"] = [parity_check(P, E, synthetic_weights, synthetic_scans, wl, dev, dev_index)
+                           for wl in ("ssv2_64x2048", "darknet53_64x2048", "darknet21_32x1024")]
   if rank == 0:
     if world == 1 and args.cpu_seconds > 0:
       out["cpu_baseline"] = cpu_baseline(r["model_name"], r["mc"], r["weights"], r["h"], r["w"], r["pvalid"],

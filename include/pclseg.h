@@ -19,7 +19,10 @@
  *   - One handle = one device + one stream; a handle is not thread-safe, independent
  *     handles are.  Forward calls are asynchronous on the handle's stream in
  *     PCLSEG_MEM_DEVICE mode (call pclseg_sync or synchronise the stream) and synchronous on
- *     return in PCLSEG_MEM_HOST mode.
+ *     return in PCLSEG_MEM_HOST mode.  Host-mode INPUTS (PCLSEG_MEM_HOST / _HOST_ASYNC) must be
+ *     complete on the CPU side when the call is made: the uploads run on the engine's own copy
+ *     streams and lanes and are NOT ordered behind work queued on the handle's stream (only
+ *     device-memory inputs are).
  *   - All activations are float32 NHWC; predictions are int32.
  */
 #ifndef PCLSEG_H_
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PCLSEG_VERSION 200 /* major*10000 + minor*100 + patch */
+#define PCLSEG_VERSION 300 /* major*10000 + minor*100 + patch */
 
 typedef struct pclseg_handle pclseg_handle;
 
@@ -154,11 +157,25 @@ int pclseg_set_weight(pclseg_handle* h, const char* keras_path, const float* dat
  * kernels and upload.  Must be called once, after every tensor has been set. */
 int pclseg_finalize(pclseg_handle* h);
 
+/* Multi-GPU start-up (one process per GPU, the scans of a batch sharded over the ranks; the reference has
+ * no device story beyond inference.py:116-118).  After pclseg_finalize the folded, packed parameters are
+ * three device arrays; export copies them (behind a small header) into ONE caller buffer — host or device,
+ * `mem` = PCLSEG_MEM_HOST / PCLSEG_MEM_DEVICE — which rank 0 broadcasts once (RCCL over xGMI); the other
+ * ranks call import on a freshly created handle of the SAME desc INSTEAD of set_weight + finalize: one
+ * device copy, no BatchNorm folding or repacking on their host cores.  import fails with
+ * PCLSEG_ERR_BAD_SHAPE when the blob was made for a different desc, arithmetic mode or library version. */
+int pclseg_packed_size(const pclseg_handle* h, size_t* bytes);
+int pclseg_export_packed(pclseg_handle* h, void* dst, size_t capacity, int mem);
+int pclseg_import_packed(pclseg_handle* h, const void* src, size_t bytes, int mem);
+
 /* Use `hip_stream` (a hipStream_t) for all subsequent work; NULL = the legacy default stream. */
 int pclseg_set_stream(pclseg_handle* h, void* hip_stream);
 /* Wait for the handle's stream.  Returns PCLSEG_ERR_RANGE if a split-f16 kernel since the last
- * check saw an out-of-range activation (with PCLSEG_FLAG_RANGE_FALLBACK: re-runs the last
- * PCLSEG_MEM_DEVICE forward call in exact float32 and returns PCLSEG_OK). */
+ * check saw an out-of-range activation: the flag is one sticky word, so EVERY asynchronous call
+ * enqueued since the previous check is suspect.  With PCLSEG_FLAG_RANGE_FALLBACK the handle remembers
+ * those calls (up to 4096) and re-runs all of them, oldest first, in exact float32 and returns
+ * PCLSEG_OK; their buffers must still be valid.  A PCLSEG_MEM_HOST forward that observes a flag raised
+ * by earlier asynchronous calls does the same (or says so in its PCLSEG_ERR_RANGE message). */
 int pclseg_sync(pclseg_handle* h);
 
 /* Page-locked host memory for the PCLSEG_MEM_HOST boundary (the reference hands NumPy arrays to

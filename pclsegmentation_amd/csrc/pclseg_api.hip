@@ -11,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -92,12 +93,19 @@ struct pclseg_handle {
   unsigned* h_range = nullptr;   // pinned host mirror
   bool fallback = false;         // PCLSEG_FLAG_RANGE_FALLBACK: both weight sets resident
   bool force_exact = false;      // fallback handle whose folded weights cannot be split (non-finite): every sweep is exact
-  struct LastCall {              // what pclseg_sync re-runs in exact mode when the guard fired
-    bool valid = false;
+  // The range flag is ONE sticky word shared by every queued call and every lane, so when it fires nobody
+  // knows which of the calls enqueued since the last check overflowed: a fallback handle remembers all
+  // of them and pclseg_sync (or the synchronous call that observes the flag) re-runs every one in exact
+  // float32, in order.  Bounded: past kMaxPending un-checked calls the repair is refused (ERR_RANGE).
+  struct PendingCall {
     const float* input = nullptr; bool raw = false; const uint8_t* mask_in = nullptr; int n = 0;
     int32_t* preds = nullptr; float* probs = nullptr; float* logits = nullptr; uint8_t* mask_out = nullptr;
     int mem = PCLSEG_MEM_DEVICE;
-  } last;
+  };
+  static constexpr size_t kMaxPending = 4096;
+  std::vector<PendingCall> pending;
+  bool pending_overflow = false;
+  int unchecked_calls = 0;       // asynchronous calls enqueued since the range flag was last read
   std::string err;
 };
 
@@ -294,6 +302,22 @@ void pack_fsq(const Op& op, const FoldIn& f, const std::vector<double>& scale, _
 }
 
 // ---- launch helpers -------------------------------------------------------------------------
+// Dynamic LDS beyond the 64 KiB default needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a
+// property of (function, DEVICE): a process may hold engines on several GPUs, so the "already raised"
+// memo is kept per device.
+hipError_t raise_lds_limit(const void* fn, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  static std::mutex m;
+  static std::set<std::pair<const void*, int>> raised;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev)) return e;
+  std::lock_guard<std::mutex> lk(m);
+  if (raised.count({fn, dev})) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) return e;
+  raised.insert({fn, dev});
+  return hipSuccess;
+}
+
 template <int MTW, int NTW, int WN, bool HEAD, bool F16, bool PAIR = false, int NW = 4>
 hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
 #define PCLSEG_GO(EPI_) \
@@ -355,14 +379,7 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
 #define PCLSEG_X(M_, N_, W_, Q_, E_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16 && epi == E_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_>; \
-    if (lds > 64 * 1024) { \
-      static bool raised = false;   /* once per kernel: dynamic LDS beyond the 64 KiB default */ \
-      if (!raised) { \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (e != hipSuccess) return e; \
-        raised = true; \
-      } \
-    } \
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds)) return e; \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a); \
     return hipGetLastError(); \
   }
@@ -379,14 +396,7 @@ hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStrea
 #define PCLSEG_X(M_, N_, W_, Q_, E_, U_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == 8 && nq == Q_ && epi == E_ && op.cin_t == 16 * U_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_, U_>; \
-    if (lds > 64 * 1024) { \
-      static bool raised = false; \
-      if (!raised) { \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (e != hipSuccess) return e; \
-        raised = true; \
-      } \
-    } \
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds)) return e; \
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a); \
     return hipGetLastError(); \
   }
@@ -502,13 +512,13 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   a.inv_pw = ((1 << 20) + a.PW - 1) / a.PW;
   a.tilesH = (a.H + a.TH - 1) / a.TH;
   a.tilesW = (a.Wconv + a.SEGW * 16 - 1) / (a.SEGW * 16);
-  static const int use_direct = getenv("PCLSEG_DIRECT1X1") ? atoi(getenv("PCLSEG_DIRECT1X1")) : 1;
+  static const int use_direct = tune_env("PCLSEG_DIRECT1X1", 1);
   if (use_direct && !exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.cin_t % 8 == 0 &&
       op.ck16 >= 32 && !a.skx && !a.res2 && !a.in_s16 && op.sub[0].nctp <= 4) {  // squeeze-like: few couts
     // LDS-free streaming GEMM; every wave owns mtw*16 pixels x ntw*16 couts
     // one block column covers ALL couts (nctp <= 4 tiles), so the input is read exactly once
     const int ntw = op.sub[0].nctp;
-    static const int splitk_min = getenv("PCLSEG_SPLITK") ? atoi(getenv("PCLSEG_SPLITK")) : 256;
+    static const int splitk_min = tune_env("PCLSEG_SPLITK", 256);
     if (splitk_min > 0 && op.cin_t >= splitk_min && ntw >= 3) {
       // deep squeezes (256..512 channels -> 48/64, 64x128 pixels): the block's four waves split
       // the channels (conv1x1_direct_kernel, SPLITK): fire6/7 14.6/18.1 -> 10.6/13.7 us,
@@ -571,7 +581,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     double wbytes = 0;
     for (int i = 0; i < op.nsub; ++i)
       wbytes += (double)op.sub[i].nkh * op.sub[i].nkw * op.cin_t * op.sub[i].nctp * 16 * 4.0;
-    static const int gm = getenv("PCLSEG_GROUP_MAJOR") ? atoi(getenv("PCLSEG_GROUP_MAJOR")) : -1;
+    static const int gm = tune_env("PCLSEG_GROUP_MAJOR", -1);
     a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
   }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
@@ -598,10 +608,10 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   }
 
   if (pair) {
-    static const int wt = getenv("PCLSEG_WT") ? atoi(getenv("PCLSEG_WT")) : 1;
+    static const int wt = tune_env("PCLSEG_WT", 1);
     // half of the blocks of an 8-wave pair take the 1x1 half first (fire8/9/10: -1.3 .. -3.4 us; the
     // 4-wave pairs measured neutral to worse)
-    static const int flip = getenv("PCLSEG_FLIP") ? atoi(getenv("PCLSEG_FLIP")) : 3;
+    static const int flip = tune_env("PCLSEG_FLIP", 3);
     a.flip_bit = op.nw == 8 ? flip : -1;
     a.wt = (wt && !a.res1 && op.nw == 4) ? 1 : 0;   // pays for the 4-wave pairs that only write (see store_quad)
     return op.up_fused ? launch_conv_up(op, epi, grid, lds, s, a) : launch_conv_pair(op, epi, grid, lds, s, a);
@@ -623,15 +633,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
 // 3x3 s(1,2) max-pool + 1x1 squeeze in one pass (Op::pool_fused); `Win` is the width BEFORE the pool.
 template <int NTW>
 hipError_t launch_pool_squeeze_n(dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
-  if (lds > 64 * 1024) {
-    static bool raised = false;   // one attribute per instantiation
-    if (!raised) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_squeeze_kernel<NTW>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      raised = true;
-    }
-  }
+  if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&pool_squeeze_kernel<NTW>), lds)) return e;
   hipLaunchKernelGGL((pool_squeeze_kernel<NTW>), grid, dim3(kConvThreads), lds, s, a);
   return hipGetLastError();
 }
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(const uint8_t* __restri
   for (size_t k = (n16 << 4) + t; k < n; k += stride) dst[k] = src[k];   // tail (or everything, if misaligned)
 }
 int zero_copy_mode() {   // bit 0: inputs, bit 1: predictions
-  static const int on = getenv("PCLSEG_ZERO_COPY") ? atoi(getenv("PCLSEG_ZERO_COPY")) : 3;   // tuning aid: 0 = DMA copies
+  static const int on = tune_env("PCLSEG_ZERO_COPY", 3);   // tuning aid: 0 = DMA copies
   return on;
 }
 bool zero_copy_enabled() { return zero_copy_mode() != 0; }
@@ -847,7 +849,7 @@ class CopyPool {
   }
  private:
   CopyPool() {
-    static const int n = getenv("PCLSEG_COPY_THREADS") ? atoi(getenv("PCLSEG_COPY_THREADS")) : 4;   // tuning aid: 1 = caller only
+    static const int n = tune_env("PCLSEG_COPY_THREADS", 4);   // tuning aid: 1 = caller only
     nworkers_ = std::max(0, std::min(n, 16) - 1);
     pid_ = getpid();
     for (int i = 0; i < nworkers_; ++i) std::thread([this] { run(); }).detach();
@@ -976,7 +978,7 @@ int sweep(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in
   const bool need_dma_out = probs != nullptr || logits != nullptr || mask_out != nullptr;
   // A kernel that reads over PCIe is bound by the link (≈ 50 GB/s), not by the GPU: it gets one small
   // block per CU, so it leaves the wave slots to the other lanes' kernels while it waits
-  static const unsigned zc_blocks = getenv("PCLSEG_ZC_BLOCKS") ? (unsigned)atoi(getenv("PCLSEG_ZC_BLOCKS")) : 16u;
+  static const unsigned zc_blocks = tune_env("PCLSEG_ZC_BLOCKS", 16u);
   NormArgs na;
   for (int i = 0; i < 5; ++i) { na.mean[i] = g.desc.mean[i]; na.std[i] = g.desc.std[i]; }
   if (multi && !host) {  // lanes start after everything already queued on the caller's stream (device inputs);
@@ -1120,6 +1122,34 @@ const char* kRangeMsg =
     "split-f16 range exceeded: an activation reached |v| >= 65504, the results of this call are not valid; "
     "create the handle with PCLSEG_FLAG_EXACT_F32 or PCLSEG_FLAG_RANGE_FALLBACK";
 
+void clear_pending(pclseg_handle* h) {
+  h->pending.clear();
+  h->pending_overflow = false;
+  h->unchecked_calls = 0;
+}
+
+// The range guard fired on a fallback handle: re-run EVERY asynchronous call enqueued since the flag was
+// last read with exact float32 products, oldest first (their buffers are the caller's and must still be
+// valid, as for any asynchronous call that has not been synchronised).  Leaves the stream idle.
+int repair_pending(pclseg_handle* h) {
+  if (h->pending_overflow) {
+    const size_t cap = pclseg_handle::kMaxPending;
+    clear_pending(h);
+    return fail(h, PCLSEG_ERR_RANGE, std::string(kRangeMsg) + fmt(" (more than %zu calls were enqueued without a pclseg_sync: "
+                                                                  "the earliest cannot be repaired)", cap));
+  }
+  std::vector<pclseg_handle::PendingCall> calls;
+  calls.swap(h->pending);
+  clear_pending(h);
+  for (const pclseg_handle::PendingCall& c : calls) {
+    const int rc = sweep(h, c.input, c.raw, c.mask_in, c.n, c.preds, c.probs, c.logits, c.mask_out, c.mem, true);
+    if (rc) { drain_after_error(h); return rc; }
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->host_async_pending = false;
+  return PCLSEG_OK;
+}
+
 int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* mask_in, int n,
                  int32_t* preds, float* probs, float* logits, uint8_t* mask_out, int mem) {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
@@ -1132,18 +1162,34 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
   DeviceGuard guard(h->device);
   int rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, h->exact || h->force_exact);
   if (rc) { drain_after_error(h); return rc; }
-  h->last.valid = false;
   if (mem != PCLSEG_MEM_HOST) {   // asynchronous: pclseg_sync reports / repairs a range overflow
-    h->last.valid = true;
-    h->last.mem = mem;
-    h->last.input = input; h->last.raw = raw; h->last.mask_in = mask_in; h->last.n = n;
-    h->last.preds = preds; h->last.probs = probs; h->last.logits = logits; h->last.mask_out = mask_out;
+    ++h->unchecked_calls;
+    if (h->fallback && !h->force_exact) {
+      if (h->pending.size() < pclseg_handle::kMaxPending) {
+        pclseg_handle::PendingCall c;
+        c.mem = mem;
+        c.input = input; c.raw = raw; c.mask_in = mask_in; c.n = n;
+        c.preds = preds; c.probs = probs; c.logits = logits; c.mask_out = mask_out;
+        h->pending.push_back(c);
+      } else {
+        h->pending_overflow = true;
+      }
+    }
     return PCLSEG_OK;
   }
+  // synchronous call: the stream is idle, so every earlier asynchronous call has finished too and the
+  // flag covers all of them
   bool fired = false;
   if ((rc = take_range_flag(h, &fired))) return rc;
-  if (!fired) return PCLSEG_OK;
-  if (!h->fallback) return fail(h, PCLSEG_ERR_RANGE, kRangeMsg);
+  if (!fired) { clear_pending(h); return PCLSEG_OK; }
+  if (!h->fallback) {
+    const int earlier = h->unchecked_calls;
+    clear_pending(h);
+    return fail(h, PCLSEG_ERR_RANGE, earlier ? std::string(kRangeMsg) + fmt(" (raised by this call or one of the %d asynchronous "
+                                                                            "calls enqueued before it: all of their outputs are suspect)", earlier)
+                                             : std::string(kRangeMsg));
+  }
+  if ((rc = repair_pending(h))) return rc;
   rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, true);   // exact float32
   if (rc) drain_after_error(h);
   return rc;
@@ -1188,6 +1234,51 @@ int run_single_op(Op* op, const FoldIn* folds, int n, int h, int w, ConvArgs a, 
                                exact ? nullptr : (const _Float16*)dw.p, (const float*)db.p, exact, nullptr));
   HIP_TRY(nullptr, hipDeviceSynchronize());
   return PCLSEG_OK;
+}
+
+// ---- packed parameter blob (pclseg_export_packed / pclseg_import_packed) ------------------------
+// [PackedHeader][bias floats][split-f16 fragments][exact-f32 fragments]: exactly the three device
+// arrays pclseg_finalize uploads, so a rank that receives the blob (one RCCL broadcast) is ready after
+// one device-to-device copy — no BatchNorm folding, no repacking, no Keras tensors on that rank.
+struct PackedHeader {
+  uint32_t magic, version;
+  int32_t arch, height, width, num_class, output_stride;
+  uint32_t math;            // bit 0: exact-f32 fragments present, bit 1: split-f16 fragments present, bit 2: force_exact
+  int64_t n_bias, n_w16, n_w32;
+  uint64_t plan_hash;       // block shapes + fragment offsets of every op: a blob only fits the plan that made it
+};
+constexpr uint32_t kPackedMagic = 0x50434c50u;   // "PLCP"
+
+uint64_t plan_hash(const Graph& g) {
+  uint64_t hsh = 1469598103934665603ull;
+  auto mix = [&](int64_t v) { for (int i = 0; i < 8; ++i) { hsh ^= (uint64_t)(v >> (8 * i)) & 0xffu; hsh *= 1099511628211ull; } };
+  mix(PCLSEG_VERSION);
+  for (const Op& op : g.ops) {
+    mix(op.kind); mix(op.ntw); mix(op.wn); mix(op.mtw); mix(op.nw); mix(op.ck16); mix(op.ck32);
+    mix(op.pair); mix(op.fsq_fused); mix(op.up_fused); mix(op.pool_fused);
+    for (int i = 0; i < op.nsub; ++i) { mix(op.sub[i].w16_off); mix(op.sub[i].w32_off); mix(op.sub[i].b_off); mix(op.sub[i].nctp); }
+    if (op.fsq_fused) { mix(op.fsq.w16_off); mix(op.fsq.b_off); }
+    if (op.up_fused) for (int i = 0; i < 2; ++i) { mix(op.up[i].w16_off); mix(op.up[i].b_off); }
+    if (op.sk_in >= 0) mix(op.sk.b_off);
+  }
+  return hsh;
+}
+
+PackedHeader packed_header(const pclseg_handle* h) {
+  PackedHeader ph;
+  memset(&ph, 0, sizeof(ph));
+  ph.magic = kPackedMagic; ph.version = PCLSEG_VERSION;
+  ph.arch = h->g.desc.arch; ph.height = h->g.desc.height; ph.width = h->g.desc.width;
+  ph.num_class = h->g.desc.num_class; ph.output_stride = h->g.desc.output_stride;
+  ph.math = (h->d_w32 ? 1u : 0u) | (h->d_w16 ? 2u : 0u) | (h->force_exact ? 4u : 0u);
+  ph.n_bias = h->g.packed_bias_floats;
+  ph.n_w16 = h->d_w16 ? h->g.packed16_halfs : 0;
+  ph.n_w32 = h->d_w32 ? h->g.packed32_floats : 0;
+  ph.plan_hash = plan_hash(h->g);
+  return ph;
+}
+size_t packed_bytes(const PackedHeader& ph) {
+  return sizeof(PackedHeader) + (size_t)ph.n_bias * 4 + (size_t)ph.n_w16 * 2 + (size_t)ph.n_w32 * 4;
 }
 
 }  // namespace
@@ -1480,6 +1571,67 @@ int pclseg_finalize(pclseg_handle* h) {
   return PCLSEG_OK;
 }
 
+int pclseg_packed_size(const pclseg_handle* h, size_t* bytes) {
+  if (!h || !bytes) return fail(const_cast<pclseg_handle*>(h), PCLSEG_ERR_BAD_ARG, "NULL argument");
+  *bytes = packed_bytes(packed_header(h));
+  return PCLSEG_OK;
+}
+
+int pclseg_export_packed(pclseg_handle* h, void* dst, size_t capacity, int mem) {
+  if (!h || !dst) return fail(h, PCLSEG_ERR_BAD_ARG, "NULL argument");
+  if (!h->finalized) return fail(h, PCLSEG_ERR_STATE, "export_packed before pclseg_finalize");
+  if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE) return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
+  const PackedHeader ph = packed_header(h);
+  if (capacity < packed_bytes(ph))
+    return fail(h, PCLSEG_ERR_BAD_ARG, fmt("buffer of %zu bytes, the packed parameters need %zu", capacity, packed_bytes(ph)));
+  DeviceGuard guard(h->device);
+  const hipMemcpyKind head = mem == PCLSEG_MEM_HOST ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
+  const hipMemcpyKind body = mem == PCLSEG_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  char* p = (char*)dst;
+  HIP_TRY(h, hipMemcpy(p, &ph, sizeof(ph), head));
+  p += sizeof(ph);
+  HIP_TRY(h, hipMemcpy(p, h->d_bias, (size_t)ph.n_bias * 4, body));
+  p += (size_t)ph.n_bias * 4;
+  if (ph.n_w16) HIP_TRY(h, hipMemcpy(p, h->d_w16, (size_t)ph.n_w16 * 2, body));
+  p += (size_t)ph.n_w16 * 2;
+  if (ph.n_w32) HIP_TRY(h, hipMemcpy(p, h->d_w32, (size_t)ph.n_w32 * 4, body));
+  return PCLSEG_OK;
+}
+
+int pclseg_import_packed(pclseg_handle* h, const void* src, size_t bytes, int mem) {
+  if (!h || !src) return fail(h, PCLSEG_ERR_BAD_ARG, "NULL argument");
+  if (h->finalized) return fail(h, PCLSEG_ERR_STATE, "import_packed on a finalized handle");
+  if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE) return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
+  if (bytes < sizeof(PackedHeader)) return fail(h, PCLSEG_ERR_BAD_ARG, "blob shorter than its header");
+  DeviceGuard guard(h->device);
+  PackedHeader got;
+  HIP_TRY(h, hipMemcpy(&got, src, sizeof(got), mem == PCLSEG_MEM_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToHost));
+  PackedHeader want = packed_header(h);
+  want.math = (want.math & 3u) | (got.math & 4u);
+  if (got.magic != kPackedMagic) return fail(h, PCLSEG_ERR_BAD_ARG, "not a packed-parameter blob (bad magic)");
+  if (memcmp(&got, &want, sizeof(got)) != 0)
+    return fail(h, PCLSEG_ERR_BAD_SHAPE,
+                fmt("packed blob does not fit this handle: blob arch %d %dx%d NC %d stride %d math %u version %u "
+                    "(%lld bias, %lld f16, %lld f32 scalars, plan %016llx); handle arch %d %dx%d NC %d stride %d math %u version %u "
+                    "(%lld, %lld, %lld, plan %016llx)",
+                    got.arch, got.height, got.width, got.num_class, got.output_stride, got.math, got.version,
+                    (long long)got.n_bias, (long long)got.n_w16, (long long)got.n_w32, (unsigned long long)got.plan_hash,
+                    want.arch, want.height, want.width, want.num_class, want.output_stride, want.math, want.version,
+                    (long long)want.n_bias, (long long)want.n_w16, (long long)want.n_w32, (unsigned long long)want.plan_hash));
+  if (bytes < packed_bytes(got)) return fail(h, PCLSEG_ERR_BAD_ARG, "blob truncated");
+  const hipMemcpyKind body = mem == PCLSEG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const char* p = (const char*)src + sizeof(got);
+  HIP_TRY(h, hipMemcpy(h->d_bias, p, (size_t)got.n_bias * 4, body));
+  p += (size_t)got.n_bias * 4;
+  if (got.n_w16) HIP_TRY(h, hipMemcpy(h->d_w16, p, (size_t)got.n_w16 * 2, body));
+  p += (size_t)got.n_w16 * 2;
+  if (got.n_w32) HIP_TRY(h, hipMemcpy(h->d_w32, p, (size_t)got.n_w32 * 4, body));
+  h->force_exact = (got.math & 4u) != 0;
+  h->finalized = true;
+  for (auto& v : h->host_w) std::vector<float>().swap(v);
+  return PCLSEG_OK;
+}
+
 int pclseg_set_stream(pclseg_handle* h, void* hip_stream) {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
   h->stream = (hipStream_t)hip_stream;
@@ -1493,16 +1645,10 @@ int pclseg_sync(pclseg_handle* h) {
   h->host_async_pending = false;
   bool fired = false;
   int rc = take_range_flag(h, &fired);
-  if (rc || !fired) return rc;
-  if (!h->fallback || !h->last.valid) return fail(h, PCLSEG_ERR_RANGE, kRangeMsg);
-  // repair: re-run the last asynchronous call with exact float32 products (its buffers are the
-  // caller's and must still be valid, as for any asynchronous call that has not been synchronised)
-  const pclseg_handle::LastCall c = h->last;
-  rc = sweep(h, c.input, c.raw, c.mask_in, c.n, c.preds, c.probs, c.logits, c.mask_out, c.mem, true);
-  if (rc) { drain_after_error(h); return rc; }
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  h->host_async_pending = false;
-  return PCLSEG_OK;
+  if (rc) return rc;
+  if (!fired) { clear_pending(h); return PCLSEG_OK; }
+  if (!h->fallback) { clear_pending(h); return fail(h, PCLSEG_ERR_RANGE, kRangeMsg); }
+  return repair_pending(h);
 }
 
 void* pclseg_host_alloc(size_t bytes) {

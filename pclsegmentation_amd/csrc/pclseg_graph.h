@@ -23,6 +23,15 @@
 
 namespace pclseg {
 
+// Experiment switches.  The shipped library carries only the decisions (the defaults below are the
+// measured best); `make tuning` (-DPCLSEG_TUNING) builds libpclseg_tuning.so, in which
+// the same names are read from the environment for A/B runs (scripts/ab_prof.sh).
+#ifdef PCLSEG_TUNING
+inline int tune_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int tune_env(const char*, int dflt) { return dflt; }
+#endif
+
 enum OpKind { OP_CONV = 0, OP_POOL = 2, OP_HEAD = 3, OP_CAM = 4 };
 
 struct WeightInfo {
@@ -164,7 +173,7 @@ inline int64_t lds_bytes_f32(const Op& op, int ck) {
 //     register tiles — 128 pixels x all or half of the couts per block, patch staged once.
 //   e <= 64  (the high-resolution layers, bandwidth bound): 4-wave blocks, many per CU.
 inline void pair_geometry(Op* op) {
-  static const int big = getenv("PCLSEG_BIGTILE") ? atoi(getenv("PCLSEG_BIGTILE")) : 1;
+  static const int big = tune_env("PCLSEG_BIGTILE", 1);
   const int nct = (op->sub[1].cout + 15) / 16;
   if (!big) return;
   // measured per layer (one-lane us, 4-wave vs 8-wave blocks): fire4/5 27.4/31.0 vs 29.7/31.5,
@@ -198,12 +207,12 @@ inline void op_geometry(Op* op) {
   // instead of once per 64, and a weight fragment feeds 8 pixel segments instead of 4.  Measured
   // (Darknet-53 64x2048 / Darknet-21 32x1024 scans/s): 4-wave 334 / 2449, 128 couts 351 / 2578,
   // 256 couts where they divide 360 / 2657, the 1x1 layers too 364 / 2675.  (tuning aid: 0..3)
-  static const int dn8 = getenv("PCLSEG_DN8") ? atoi(getenv("PCLSEG_DN8")) : 3;
+  static const int dn8 = tune_env("PCLSEG_DN8", 3);
   if (dn8 && op->kind == OP_CONV && op->nsub == 1 && !op->pair && nct % 8 == 0 && (dn8 >= 3 || !op_is_flat(*op)) && op->sk_in < 0) {
     op->nw = 8; op->wn = 4; op->ntw = 2; op->mtw = 4;
     if (dn8 >= 2 && nct % 16 == 0) { op->wn = 8; op->mtw = 8; }   // 128 px x 256 couts
   }
-  static const int geom_only = getenv("PCLSEG_FSQ_GEOM_ONLY") ? atoi(getenv("PCLSEG_FSQ_GEOM_ONLY")) : 0;   // debug
+  static const int geom_only = tune_env("PCLSEG_FSQ_GEOM_ONLY", 0);   // debug
   if (op->fsq_fused || (geom_only && op->pair && (nct == 16 || nct == 12 || nct == 8) && op->res1 < 0)) {   // 8 waves on a 64-pixel tile, all couts of both halves in the block
     op->nw = 8;
     if (nct == 16) { op->wn = 8; op->ntw = 2; op->mtw = 4; }        // 64 px x (256 + 256) couts
@@ -212,7 +221,8 @@ inline void op_geometry(Op* op) {
     else if (nct == 4) { op->wn = 4; op->ntw = 1; op->mtw = 4; }    // 128 px x (64 + 64)
     else { op->wn = 2; op->ntw = 1; op->mtw = 4; }                  // 256 px x (32 + 32)
   }
-  if (!op->fsq_fused) if (const char* ov = getenv("PCLSEG_GEOM")) {  // tuning aid: "subname=ntw,wn,mtw[,nw];subname=..."
+#ifdef PCLSEG_TUNING
+  if (!op->fsq_fused) if (const char* ov = getenv("PCLSEG_GEOM")) {  // "subname=ntw,wn,mtw[,nw];subname=..."
     const std::string key = op->sub[0].name + "=";
     const char* hit = strstr(ov, key.c_str());
     int a = 0, b = 0, c = 0, d = 4;
@@ -221,6 +231,7 @@ inline void op_geometry(Op* op) {
       if (got >= 3) { op->ntw = a; op->wn = b; op->mtw = c; op->nw = got == 4 ? d : 4; }
     }
   }
+#endif
   const int group = op->ntw * op->wn;
   for (int i = 0; i < op->nsub; ++i) {
     const int n = (op->sub[i].cout + 15) / 16;
@@ -230,7 +241,7 @@ inline void op_geometry(Op* op) {
   // f16 mode: 40 KiB keeps four blocks per CU resident (160 KiB LDS); worth a second channel chunk
   // from 64 input channels up (head 77 -> 68 us), not for the 48-channel squeezes (35 -> 36 us).
   // Merged FIRE pairs and 8-wave blocks take the whole patch in one chunk.
-  static const int64_t b64 = getenv("PCLSEG_LDS_BUDGET64") ? atoi(getenv("PCLSEG_LDS_BUDGET64")) : 40 * 1024;   // tuning aid
+  static const int64_t b64 = tune_env("PCLSEG_LDS_BUDGET64", 40 * 1024);   // tuning aid
   const int64_t budget16 = (op->cin_t >= 64 && !op->pair && op->nw == 4) ? b64 : budget;
   op->ck16 = 64;
   while (op->ck16 > 16 && lds_bytes_f16(*op, op->ck16) > budget16) op->ck16 /= 2;
@@ -710,8 +721,8 @@ inline void plan_workspace(Graph* g) {
 // whose input is in that format runs as merged blocks (conv_kernel PAIR).
 inline void assign_formats(Graph* g) {
   if (g->desc.flags & PCLSEG_FLAG_EXACT_F32) return;
-  static const int s16 = getenv("PCLSEG_S16") ? atoi(getenv("PCLSEG_S16")) : 1;   // tuning aid: 0 = all float32
-  static const int pair = getenv("PCLSEG_PAIR") ? atoi(getenv("PCLSEG_PAIR")) : 1;
+  static const int s16 = tune_env("PCLSEG_S16", 1);   // tuning aid: 0 = all float32
+  static const int pair = tune_env("PCLSEG_PAIR", 1);
   if (!s16) return;
   const int nt = (int)g->tensors.size();
   std::vector<int> readers(nt, 0), other(nt, 0), producer(nt, -1), reader_op(nt, -1);

@@ -24,6 +24,7 @@ def init_process_group(backend=None):
   backend defaults to nccl (= RCCL on ROCm) when a GPU is visible, else gloo."""
   rank, local_rank, world = env_world()
   if world > 1 and not dist.is_initialized():
+    bind_rank(local_rank)            # (sysfs + sched_setaffinity only; nothing below has touched HIP yet)
     if backend is None:   # PCLSEG_DIST_BACKEND=gloo: test aid (several ranks sharing one GPU)
       backend = os.environ.get("PCLSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -73,6 +74,66 @@ def broadcast_weights(spec, weights, src=0, device=None):
     blob = torch.empty(n, dtype=torch.float32, device=device)
   dist.broadcast(blob, src=src)
   return unpack_weights(spec, blob.cpu().numpy())
+
+
+def broadcast_engine(model, height, width, flags=0, src=0, device=None):
+  """Every rank gets a ready engine of ``model`` at height x width; only rank ``src`` needs the
+  weights.  Rank ``src`` folds BatchNorm and packs the MFMA fragments once (pclseg_finalize), exports
+  the packed device arrays into one buffer (pclseg_export_packed), ONE broadcast moves it — over
+  RCCL/xGMI device to device — and the other ranks import it (pclseg_import_packed: a device copy).
+  Darknet-53: one 216 MB collective instead of eight host-side fold + repack passes of 53 M parameters."""
+  from . import engine as _engine
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return model.engine(height, width, flags)
+  on_gpu = dist.get_backend() == "nccl"
+  if on_gpu and device is None:
+    device = torch.device("cuda", torch.cuda.current_device())
+  if not on_gpu:
+    device = torch.device("cpu")     # gloo moves host tensors (ranks sharing one GPU in tests)
+  is_src = dist.get_rank() == src
+  eng = model.engine(height, width, flags) if is_src else _engine.Engine(model.engine_desc(height, width, flags))
+  blob = torch.empty(eng.packed_size(), dtype=torch.uint8, device=device)
+  if is_src:
+    eng.export_packed(blob)
+  dist.broadcast(blob, src=src)
+  if not is_src:
+    eng.import_packed(blob)
+    model.adopt_engine(eng, height, width, flags)
+  return eng
+
+
+def bind_rank(local_rank):
+  """Pin this rank process to the CPU cores next to its GPU.  Must run BEFORE the process touches HIP
+  (it only reads sysfs and calls sched_setaffinity): KFD topology node order is the HIP device order,
+  a node's PCI address comes from its `domain` / `location_id` properties, and
+  /sys/bus/pci/devices/<bdf>/local_cpulist names the NUMA-local cores.  A speed hint only: any
+  failure — or a *_VISIBLE_DEVICES variable that re-maps device numbers — leaves the affinity alone."""
+  import glob
+  if any(os.environ.get(v) for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+    return None
+  try:
+    gpus = []
+    nodes = sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda p: int(os.path.basename(p)))
+    for node in nodes:
+      props = dict(l.split()[:2] for l in open(os.path.join(node, "properties")).read().splitlines()
+                   if len(l.split()) >= 2)
+      if int(props.get("simd_count", "0")) > 0:
+        loc = int(props["location_id"])
+        gpus.append("%04x:%02x:%02x.%x" % (int(props.get("domain", "0")), (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))
+    if not gpus:
+      return None
+    bdf = gpus[local_rank % len(gpus)]
+    cpus = set()
+    for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
+      lo, _, hi = part.partition("-")
+      cpus.update(range(int(lo), int(hi or lo) + 1))
+    allowed = cpus & os.sched_getaffinity(0)
+    if allowed:
+      os.sched_setaffinity(0, allowed)
+      return sorted(allowed)
+  except (OSError, ValueError, KeyError):
+    pass
+  return None
 
 
 def gather_predictions(local_preds, n_total, dst=0):

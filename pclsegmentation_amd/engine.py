@@ -31,6 +31,7 @@ ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
 EXPORTS = [
   "pclseg_version", "pclseg_last_error", "pclseg_plan", "pclseg_create", "pclseg_destroy",
   "pclseg_num_weights", "pclseg_weight_info", "pclseg_set_weight", "pclseg_finalize",
+  "pclseg_packed_size", "pclseg_export_packed", "pclseg_import_packed",
   "pclseg_set_stream", "pclseg_sync", "pclseg_host_alloc", "pclseg_host_free", "pclseg_forward", "pclseg_forward_raw",
   "pclseg_num_tensors", "pclseg_tensor_info", "pclseg_read_tensor", "pclseg_op_normalize",
   "pclseg_op_conv2d", "pclseg_op_conv2d_transpose", "pclseg_op_max_pool", "pclseg_op_head",
@@ -91,6 +92,9 @@ def load_library():
                                      ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
   lib.pclseg_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), i32]
   lib.pclseg_finalize.argtypes = [vp]
+  lib.pclseg_packed_size.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+  lib.pclseg_export_packed.argtypes = [vp, vp, ctypes.c_size_t, i32]
+  lib.pclseg_import_packed.argtypes = [vp, vp, ctypes.c_size_t, i32]
   lib.pclseg_set_stream.argtypes = [vp, vp]
   lib.pclseg_sync.argtypes = [vp]
   lib.pclseg_host_alloc.argtypes = [ctypes.c_size_t]
@@ -269,6 +273,32 @@ class Engine:
 
   def finalize(self):
     check(self.lib.pclseg_finalize(self._h), self._h)
+    self.finalized = True
+
+  # -- packed parameters (multi-GPU start-up: rank 0 exports, the others import the broadcast blob)
+  def packed_size(self):
+    n = ctypes.c_size_t()
+    check(self.lib.pclseg_packed_size(self._h, ctypes.byref(n)), self._h)
+    return int(n.value)
+
+  @staticmethod
+  def _blob(buf):
+    """-> (address, bytes, mem) of a uint8 NumPy array or torch tensor (host or device)."""
+    if isinstance(buf, np.ndarray):
+      if buf.dtype != np.uint8 or not buf.flags["C_CONTIGUOUS"]:
+        raise ValueError("pclseg: packed blob must be a C-contiguous uint8 array")
+      return _ptr(buf), buf.size, MEM_HOST
+    if str(buf.dtype) != "torch.uint8" or not buf.is_contiguous():
+      raise ValueError("pclseg: packed blob must be a contiguous uint8 tensor")
+    return _ptr(buf), buf.numel(), (MEM_DEVICE if buf.is_cuda else MEM_HOST)
+
+  def export_packed(self, buf):
+    p, n, mem = self._blob(buf)
+    check(self.lib.pclseg_export_packed(self._h, p, n, mem), self._h)
+
+  def import_packed(self, buf):
+    p, n, mem = self._blob(buf)
+    check(self.lib.pclseg_import_packed(self._h, p, n, mem), self._h)
     self.finalized = True
 
   # -- execution

@@ -48,9 +48,11 @@ class MeanIoU:
     self.name = name
     self._dev = torch.device("cuda", device)
     self._cm = torch.zeros((self.num_classes, self.num_classes), dtype=torch.int64, device=self._dev)
+    self._seen = 0
 
   def reset_state(self):
     self._cm.zero_()
+    self._seen = 0
 
   def update_state(self, label, predictions):
     """Host arrays or device tensors.  Labels outside [0, num_classes) are NOT counted (tf.metrics.
@@ -60,9 +62,9 @@ class MeanIoU:
     prd = torch.as_tensor(np.asarray(predictions) if not hasattr(predictions, "is_cuda") else predictions)
     lab = lab.to(self._dev, dtype=torch.int32).contiguous()
     prd = prd.to(self._dev, dtype=torch.int32).contiguous()
-    self._seen = getattr(self, "_seen", 0) + lab.numel()
     if lab.numel() != prd.numel():
       raise ValueError("label and predictions differ in size: %d vs %d" % (lab.numel(), prd.numel()))
+    self._seen += lab.numel()
     _engine.op_confusion_matrix(lab, prd, lab.numel(), self.num_classes, self._cm,
                                 torch.cuda.current_stream(self._dev).cuda_stream)
 
@@ -73,7 +75,7 @@ class MeanIoU:
   @property
   def ignored(self):
     """Pixels whose label or prediction was outside [0, num_classes) and therefore not counted."""
-    return int(getattr(self, "_seen", 0) - int(self._cm.sum().item()))
+    return int(self._seen - int(self._cm.sum().item()))
 
   def result(self):
     cm = self.total_cm.astype(np.float64)

@@ -95,16 +95,25 @@ class PCLSegmentationNetwork:
     if key not in self._engines:
       if self.weights is None:
         raise RuntimeError("model has no weights: call set_weights / init_weights / load_weights")
-      mc = self.mc
-      desc = _engine.make_desc(self.arch_name(), h, w, mc.NUM_CLASS, mc.CLASSES.index("None"),
-                               mc.INPUT_MEAN, mc.INPUT_STD,
-                               output_stride=mc.get("OUTPUT_STRIDE", 16), device=self.device,
-                               micro_batch=self.micro_batch, flags=flags)
-      eng = _engine.Engine(desc)
+      eng = _engine.Engine(self.engine_desc(h, w, flags))
       eng.set_weights(self.weights)
       eng.finalize()
       self._engines[key] = eng
     return self._engines[key]
+
+  def engine_desc(self, height=None, width=None, flags=0):
+    """pclseg_desc of this model at a given range-image size (what pclseg_create takes)."""
+    mc = self.mc
+    return _engine.make_desc(self.arch_name(), int(height or self.ZENITH_LEVEL), int(width or self.AZIMUTH_LEVEL),
+                             mc.NUM_CLASS, mc.CLASSES.index("None"), mc.INPUT_MEAN, mc.INPUT_STD,
+                             output_stride=mc.get("OUTPUT_STRIDE", 16), device=self.device,
+                             micro_batch=self.micro_batch, flags=flags)
+
+  def adopt_engine(self, eng, height, width, flags=0):
+    """Register an engine whose parameters arrived as a packed blob (distributed.broadcast_engine):
+    this rank never holds the Keras tensors."""
+    self._engines[(int(height), int(width), flags)] = eng
+    return eng
 
   # ---- the model call
   def call(self, inputs, training=False, mask=None, return_probabilities=True):

@@ -1,5 +1,5 @@
 """Rank process of tests/test_gpu_distributed.py (started by torch.distributed.run): the engine's
-multi-GPU path as bench.py / a serving job uses it — one weight broadcast, then every rank runs ITS
+multi-GPU path as bench.py / a serving job uses it — one broadcast of the PACKED parameters, then every rank runs ITS
 contiguous shard of the batch with no data-path collective and writes its predictions to a file.
 
 usage: dist_worker.py <out_dir> <n_scans> <h> <w>"""
@@ -25,12 +25,12 @@ def main():
   torch.cuda.set_device(dev_index)
   dev = torch.device("cuda", dev_index)
   mc, model = P.load_model_config("squeezesegv2", "squeezesegv2", height=h, width=w, device=dev_index)
-  spec = model.weight_spec()
-  weights = synthetic_weights(spec, 4321) if rank == 0 else None        # only rank 0 owns the weights
-  model.set_weights(D.broadcast_weights(spec, weights, src=0, device=dev))
+  if rank == 0:                                  # only rank 0 ever holds the Keras tensors:
+    model.set_weights(synthetic_weights(model.weight_spec(), 4321))
+  eng = D.broadcast_engine(model, h, w, src=0, device=dev)   # folded + packed once, one broadcast, import elsewhere
+  assert rank == 0 or model.weights is None
   raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=99)  # the job's whole batch
   lo, hi = D.shard_range(n, rank, world)
-  eng = model.engine(h, w)
   scans = torch.from_numpy(raw[lo:hi]).to(dev)
   preds = torch.empty((hi - lo, h, w), dtype=torch.int32, device=dev)
   logits = torch.empty((hi - lo, h, w, mc.NUM_CLASS), dtype=torch.float32, device=dev)

@@ -68,3 +68,27 @@ def test_two_process_broadcast_and_sharding():
   assert res[0][1] == want and res[1][1] == want          # rank 1 received rank 0's weights
   assert res[0][2] == (0, 3) and res[1][2] == (3, 5)      # disjoint, covering
   assert res[0][3] == [0, 10, 20, 31, 41] and res[1][3] is None
+
+
+def test_rank_binding_and_gpu_census_never_touch_hip():
+  """bench.py's launcher and distributed.bind_rank decide from sysfs / the environment only; both must
+  work (and do nothing harmful) on a box without a GPU."""
+  import importlib.util
+  import sys as _sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  n = bench.visible_gpu_count()
+  assert isinstance(n, int) and n >= 0
+  before = os.sched_getaffinity(0)
+  got = D.bind_rank(0)
+  after = os.sched_getaffinity(0)
+  assert got is None or (set(got) == after and after <= before)
+  os.sched_setaffinity(0, before)
+  os.environ["HIP_VISIBLE_DEVICES"] = "0"
+  try:
+    assert D.bind_rank(3) is None and os.sched_getaffinity(0) == before      # re-mapped device numbers: hands off
+    assert bench.visible_gpu_count() <= 1
+  finally:
+    del os.environ["HIP_VISIBLE_DEVICES"]

@@ -36,9 +36,10 @@ def _rank_env():
   return env
 
 
-def test_two_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path):
-  n, h, w = 7, 32, 240          # 7 scans over 2 ranks: shards [0,4) and [4,7)
-  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+@pytest.mark.parametrize("world,n", [(2, 7), (8, 19)])   # 7 scans over 2 ranks: [0,4) [4,7); 19 over 8: ragged 3,3,3,2,...
+def test_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path, world, n):
+  h, w = 32, 240
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
          os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(n), str(h), str(w)]
   r = subprocess.run(cmd, env=_rank_env(), capture_output=True, text=True, timeout=600)
@@ -52,10 +53,10 @@ def test_two_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path):
   logits = np.empty((n, h, w, mc.NUM_CLASS), np.float32)
   eng.forward_raw(raw, n, preds, None, logits, None, mem=E.MEM_HOST)
   seen = np.zeros(n, bool)
-  for rank in range(2):
+  for rank in range(world):
     g = np.load(str(tmp_path / ("rank%d.npz" % rank)))
     lo, hi = int(g["lo"]), int(g["hi"])
-    assert (lo, hi) == D.shard_range(n, rank, 2)
+    assert (lo, hi) == D.shard_range(n, rank, world)
     assert np.array_equal(g["preds"], preds[lo:hi]) and np.array_equal(g["logits"], logits[lo:hi])
     seen[lo:hi] = True
   assert seen.all()
@@ -76,3 +77,50 @@ def test_bench_launches_its_own_ranks(cuda):
   out = json.loads(lines[0])
   assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
   assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out
+
+
+def test_bench_strong_scaling_mode(cuda):
+  """`--scaling strong`: a FIXED global batch sharded over the ranks by contiguous ranges (SURVEY.md §8(e),
+  BASELINE configs[3] is 256 scans over 8 GPUs); here 10 scans over 4 ranks sharing the one GPU."""
+  env = _rank_env()
+  env.pop("PCLSEG_DIST_BACKEND")
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+         "--workload", "ssv2_32x240", "--cpu-seconds", "0", "--scaling", "strong", "--global-batch", "10"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+  assert out["n_gpus"] == 4 and out["scaling"] == "strong" and out["config"]["global_batch"] == 10
+  assert out["config"]["batch_per_gpu"] == 3       # rank 0's share of 10 over 4: 3,3,2,2
+  assert abs(out["value"] - 10 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-2
+
+
+def test_packed_parameters_round_trip(cuda):
+  """pclseg_export_packed -> pclseg_import_packed (host and device buffers): the importing handle, which
+  never saw a Keras tensor, produces bit-identical outputs; a blob made for another desc is refused."""
+  import torch
+  h, w = 32, 240
+  mc, model = P.load_model_config("darknet21", "darknet21", height=h, width=w)
+  model.init_weights(4321)
+  raw = synthetic_scans(3, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=5)
+  for flags in (0, E.FLAG_EXACT_F32, E.FLAG_RANGE_FALLBACK):
+    src = model.engine(h, w, flags)
+    want_p, want_l = np.empty((3, h, w), np.int32), np.empty((3, h, w, mc.NUM_CLASS), np.float32)
+    src.forward_raw(raw, 3, want_p, None, want_l, None, mem=E.MEM_HOST)
+    nbytes = src.packed_size()
+    for blob in (np.empty(nbytes, np.uint8), torch.empty(nbytes, dtype=torch.uint8, device="cuda")):
+      src.export_packed(blob)
+      dst = E.Engine(model.engine_desc(h, w, flags))
+      dst.import_packed(blob)
+      p, l = np.empty_like(want_p), np.empty_like(want_l)
+      dst.forward_raw(raw, 3, p, None, l, None, mem=E.MEM_HOST)
+      assert np.array_equal(p, want_p) and np.array_equal(l, want_l)
+      with pytest.raises(RuntimeError):
+        dst.import_packed(blob)                      # already finalized
+      dst.close()
+    other = E.Engine(model.engine_desc(h, 256, flags))
+    with pytest.raises(ValueError, match="does not fit"):
+      other.import_packed(blob)
+    other.close()
+    with pytest.raises(ValueError):
+      src.export_packed(np.empty(nbytes - 1, np.uint8))
+  model._drop_engines()

@@ -28,7 +28,10 @@ def test_confusion_matrix_bit_exact(cuda, nc, count):
   for got, ref in zip(ev.confusion_matrix_to_iou_recall_precision(m.total_cm), O.iou_recall_precision(want)):
     assert np.allclose(got, ref, rtol=0, atol=1e-12)
   m.reset_state()
-  assert m.total_cm.sum() == 0
+  assert m.total_cm.sum() == 0 and m.ignored == 0       # the out-of-range tally restarts with the matrix
+  with pytest.raises(ValueError):
+    m.update_state(labels[:10], preds[:9])
+  assert m.ignored == 0                                   # a rejected update is not counted as seen
 
 
 def test_iou_known_answer(cuda):

@@ -191,19 +191,46 @@ def test_full_size_kitti_shape(cuda):
   assert np.array_equal(p2, preds) and np.array_equal(l2, logits)
 
 
+def test_c1_reference_sample_dataset_all_32_scans(cuda):
+  """BASELINE configs[0]: SqueezeSegV2 / 11 classes on ALL 32 real scans of the reference's
+  dataset_samples/sample_dataset/train (32x240; fixture = the inputs, made by make_c1_fixture.py), as
+  one batch of 32 and in the reference's own loop shape — one scan per call (inference.py:44-75) —
+  against the float64 oracle, both arithmetic modes."""
+  g = np.load(os.path.join(GOLDEN, "c1_sample_dataset_train_32x240.npz"))
+  raw = g["raw"]
+  assert raw.shape == (32, 32, 240, 5)
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  none_index = mc.CLASSES.index("None")
+  lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  _, opred, ologits = O.forward("squeezesegv2", model.weights, lidar, omask, none_index, dtype=np.float64)
+  srt = np.sort(ologits, -1)
+  margin = srt[..., -1] - srt[..., -2]
+  for flags in (0, E.FLAG_EXACT_F32):
+    preds, logits, mask, _ = run_engine(model, raw, flags=flags)
+    assert np.array_equal(mask, omask)
+    check_against(preds, logits, mask, ologits, opred, margin, none_index)
+    for i in (0, 13, 31):                                   # the reference's batch-1 loop
+      p1, l1, _, _ = run_engine(model, raw[i:i + 1], flags=flags)
+      assert np.array_equal(p1[0], preds[i]) and np.array_equal(l1[0], logits[i])
+    model._drop_engines()
+
+
 def test_full_size_darknet21_nuscenes_shape(cuda):
   """BASELINE configs[4]: Darknet-21 at 32x1024 — one scan against the oracle plus batch
   invariance."""
   mc, model = P.load_model_config("darknet21", "darknet21", height=32, width=1024)
   model.init_weights(4321)
-  raw = synthetic_scans(5, 32, 1024, mc.INPUT_MEAN, mc.INPUT_STD, 0.59, seed=1234)
+  raw = synthetic_scans(64, 32, 1024, mc.INPUT_MEAN, mc.INPUT_STD, 0.59, seed=1234)   # the config's batch 64
   preds, logits, mask, _ = run_engine(model, raw)
+  assert (preds[~mask] == 10).all() and preds.min() >= 0 and preds.max() < 11
   lidar, omask = O.normalize_and_mask(raw[2:3], mc.INPUT_MEAN, mc.INPUT_STD)
   _, opred, ologits = O.forward("darknet21", model.weights, lidar, omask, 10, num_layers=21, dtype=np.float64)
   srt = np.sort(ologits[0], -1)
   check_against(preds[2], logits[2], mask[2], ologits[0], opred[0], (srt[..., -1] - srt[..., -2]), 10)
-  p1, l1, _, _ = run_engine(model, raw[2:3])
-  assert np.array_equal(p1[0], preds[2]) and np.array_equal(l1[0], logits[2])
+  for i in (2, 40, 63):
+    p1, l1, _, _ = run_engine(model, raw[i:i + 1])
+    assert np.array_equal(p1[0], preds[i]) and np.array_equal(l1[0], logits[i])
 
 
 def test_inference_cli_reads_a_savedmodel_directory(cuda, tmp_path):
@@ -344,6 +371,84 @@ def test_split_f16_range_guard_and_exact_fallback(cuda):
     else:
       eng.sync()
       assert np.array_equal(d_preds.cpu().numpy(), p_exact)
+  model._drop_engines()
+
+
+def test_range_fallback_repairs_every_unsynced_call(cuda):
+  """the range flag is one sticky word shared by all queued calls.  Two device calls are
+  enqueued before one sync — the FIRST overflows the f16 range, the second (an all-invalid scan: zero
+  input, activations = biases) does not.  A fallback handle must repair the first call too, not only
+  the last one; so must a synchronous MEM_HOST call that observes a flag raised by a pending device call."""
+  import torch
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  w = dict(model.weights)
+  w["conv1/kernel"] = w["conv1/kernel"] * np.float32(3.0e4)
+  model.set_weights(w)
+  hot = synthetic_scans(2, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=13)
+  cold = hot.copy()
+  cold[..., 4] = 0.0                                      # depth 0 everywhere: every pixel masked, lidar = 0
+  p_hot, _, _, _ = run_engine(model, hot, flags=E.FLAG_EXACT_F32)
+  p_cold, _, _, _ = run_engine(model, cold, flags=E.FLAG_EXACT_F32)
+  model._drop_engines()
+  run_engine(model, cold)                                 # the premise: the cold scan alone stays in range
+  model._drop_engines()
+  eng = model.engine(32, 240, E.FLAG_RANGE_FALLBACK)
+  eng.set_stream(torch.cuda.current_stream().cuda_stream)
+  d_hot, d_cold = torch.from_numpy(hot).cuda(), torch.from_numpy(cold).cuda()
+  o1 = torch.full((2, 32, 240), -7, dtype=torch.int32, device="cuda")
+  o2 = torch.full((2, 32, 240), -7, dtype=torch.int32, device="cuda")
+  eng.forward_raw(d_hot, 2, o1, None, None, None, mem=E.MEM_DEVICE)    # overflows
+  eng.forward_raw(d_cold, 2, o2, None, None, None, mem=E.MEM_DEVICE)   # does not
+  eng.sync()
+  assert np.array_equal(o1.cpu().numpy(), p_hot), "the earlier of two un-synchronised calls was not repaired"
+  assert np.array_equal(o2.cpu().numpy(), p_cold)
+  # a synchronous host call behind a pending device call consumes the flag: both are repaired
+  o1.fill_(-7)
+  h_out = np.empty((2, 32, 240), np.int32)
+  eng.forward_raw(d_hot, 2, o1, None, None, None, mem=E.MEM_DEVICE)
+  eng.forward_raw(np.ascontiguousarray(cold), 2, h_out, None, None, None, mem=E.MEM_HOST)
+  assert np.array_equal(h_out, p_cold)
+  eng.sync()
+  assert np.array_equal(o1.cpu().numpy(), p_hot)
+  # without the fallback the synchronous call reports the flag and says earlier calls are suspect
+  model._drop_engines()
+  eng = model.engine(32, 240, 0)
+  eng.set_stream(torch.cuda.current_stream().cuda_stream)
+  eng.forward_raw(d_hot, 2, o1, None, None, None, mem=E.MEM_DEVICE)
+  with pytest.raises(FloatingPointError, match="asynchronous"):
+    eng.forward_raw(np.ascontiguousarray(cold), 2, h_out, None, None, None, mem=E.MEM_HOST)
+  eng.sync()
+  model._drop_engines()
+
+
+def test_finalize_rejects_weights_the_split_cannot_carry(cuda):
+  """a BatchNorm-folded weight that is not finite (moving_variance = -eps makes
+  gamma / sqrt(var + eps) infinite) cannot be split into f16 hi/lo (inf - inf = NaN): finalize says so
+  instead of shipping NaN fragments; a RANGE_FALLBACK handle runs such a model in exact float32."""
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.init_weights(4321)
+  w = dict(model.weights)
+  v = w["fire2/expand3x3_bn/moving_variance"].copy()
+  v[3] = np.float32(-1e-3)
+  w["fire2/expand3x3_bn/moving_variance"] = v
+  model.set_weights(w)
+  raw = synthetic_scans(1, 32, 240, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=5)
+  with pytest.raises(FloatingPointError, match="not finite"):
+    run_engine(model, raw)
+  model._drop_engines()
+  p_exact, l_exact, _, _ = run_engine(model, raw, flags=E.FLAG_EXACT_F32)
+  model._drop_engines()
+  p_fb, l_fb, _, _ = run_engine(model, raw, flags=E.FLAG_RANGE_FALLBACK)
+  assert np.array_equal(p_fb, p_exact) and np.array_equal(l_fb, l_exact, equal_nan=True)
+  model._drop_engines()
+  # huge but finite folded weights are fine: the per-channel scale brings them into range
+  w = dict(model.weights)
+  w["fire2/expand3x3_bn/moving_variance"] = model.weights["fire2/expand3x3_bn/moving_variance"] * 0 + np.float32(1.0)
+  g = w["fire2/expand3x3_bn/gamma"].copy(); g[3] = np.float32(3.0e6)
+  w["fire2/expand3x3_bn/gamma"] = g
+  model.set_weights(w)
+  run_engine(model, raw, flags=E.FLAG_RANGE_FALLBACK)     # finalize accepts (whether the ACTIVATIONS overflow is the range guard's business)
   model._drop_engines()
 
 

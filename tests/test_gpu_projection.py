@@ -98,8 +98,15 @@ def test_label_map_and_converter_sample_match_reference(cuda):
                       fov_down=float(g["fov_down"]))
   scan.set_points(g["points"][:, :3], g["points"][:, 3])
   scan.set_label(g["labels"].astype(np.int64), learning_map=lm)
-  same = scan.proj_idx == g["proj_idx"]
-  assert same.mean() > 0.999
+  idx, gold = scan.proj_idx, g["proj_idx"]
+  same = idx == gold
+  # enumerate the differing pixels: each must involve a point on a float32 cell border (_border_points)
+  border = _border_points(g["points"], int(g["H"]), int(g["W"]), float(g["fov_up"]), float(g["fov_down"]))
+  bad = np.argwhere(~same)
+  print("kitti labels: %d of %d pixels differ from the reference (%d border points)" % (len(bad), same.size, int(border.sum())))
+  for y, x in bad:
+    assert any(border[i] for i in (idx[y, x], gold[y, x]) if i >= 0), ("non-border mismatch at", y, x)
+  assert len(bad) <= 2 * border.sum()
   final = scan.sample()
   assert final.shape == g["final"].shape
   assert np.array_equal(final[same].astype(np.float64), g["final"][same])
@@ -114,9 +121,18 @@ def test_front_view_information_map_matches_reference(cuda):
   want = f["info"]
   assert got.shape == want.shape and got.dtype == np.float64
   diff = np.argwhere((got != want).any(-1))
-  # float64 atan2 on both sides: at most a handful of column-border points may differ by libm
+  # float64 atan2 on both sides; a pixel may differ only where a point's continuous column
+  # (left_phi - atan2(y, x)) / dphi sits within a few float64 ulps of an integer (device libm vs glibc):
+  # enumerate the differing pixels and find such a point in the pixel or its column neighbours
   print("front map: %d of %d pixels differ" % (len(diff), 32 * 240))
-  assert len(diff) <= 4
+  pcl = f["pcl"].astype(np.float64)
+  left, right = np.radians(24.32), np.radians(22.23)       # convert_validation_pcd_to_npy.py:99-100
+  col = (left - np.arctan2(pcl[:, 1], pcl[:, 0])) / ((right + left) / 240)
+  on_border = np.abs(col - np.round(col)) < 64 * np.spacing(240.0)
+  for y, x in diff:
+    cands = on_border & (np.abs(np.round(col) - x) <= 1)
+    assert cands.any(), ("front-view mismatch without a column-border point", y, x)
+  assert len(diff) <= 2 * max(1, int(on_border.sum()))
   ok = ~(got != want).any(-1)
   assert np.array_equal(got[ok], want[ok])
   assert np.array_equal(got[..., 6], (got[..., 4] > 0).astype(np.float64))

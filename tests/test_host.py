@@ -86,7 +86,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == set(E.EXPORTS)
   for name in declared:
     assert hasattr(lib, name), name
-  assert lib.pclseg_version() == 200
+  assert lib.pclseg_version() == 300
 
 
 PLAN_CASES = [
