@@ -84,9 +84,9 @@ typedef enum pclseg_mem {
  *   PCLSEG_MATH_F16X3: each float32 operand v is split hi = f16(v), lo = f16(v - hi) and a
  *     product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16.  The pair carries 22 significant
  *     bits while lo is a normal half, i.e. for |v| >= 2^-3; below that the ABSOLUTE error is 2^-25.
- *     Weights are therefore pre-scaled per output channel by a power of two (largest |w| of the
- *     channel -> [2^12, 2^13), undone exactly in the float32 epilogue), so every weight down to 2^-15
- *     of its channel's maximum keeps 22 bits; activations are split as they are (O(1) values after
+ *     Weights are therefore pre-scaled by a power of two per tile of 16 output channels (largest |w|
+ *     of the tile -> [2^12, 2^13), undone exactly in the float32 epilogue), so every weight down to 2^-15
+ *     of its tile's maximum keeps 22 bits; activations are split as they are (O(1) values after
  *     BatchNorm: absolute error 2^-25 where |v| < 1/8).  Measured: logits within ~1e-5 of the float64
  *     oracle on all three networks (bench.py `parity_check`).  Default.  Requires |activation| < 65504: every kernel that
  *     splits a value checks it, a violation sets a sticky flag on the device and the call that
@@ -247,9 +247,9 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
 
 /* CPU only (no GPU needed): what the split-f16 matrix-core path multiplies by.  Packs a Keras
  * Conv2D kernel (kh,kw,Cin,Cout; 1x1 or 3x3) exactly as pclseg_finalize does in PCLSEG_MATH_F16X3 mode —
- * per output channel a power-of-two scale 2^k that puts the channel's largest |w| into [2^12, 2^13),
- * then hi = f16(w 2^k), lo = f16(w 2^k - hi) — and writes, in the same Keras layout, the value the
- * fragments represent: recon = (hi + lo) 2^-k (float64, exact).  exponents (optional, [Cout]) receives k.
+ * per tile of 16 output channels a power-of-two scale 2^k that puts the tile's largest |w| into
+ * [2^12, 2^13), then hi = f16(w 2^k), lo = f16(w 2^k - hi) — and writes, in the same Keras layout, the value
+ * the fragments represent: recon = (hi + lo) 2^-k (float64, exact).  exponents (optional, [Cout]) receives k.
  * Reference arithmetic this stands in for: TensorFlow float32 Conv2D (requirements.txt:1). */
 int pclseg_op_split_f16_roundtrip(const float* kernel, int kh, int kw, int cin, int cout, double* recon,
                                   int32_t* exponents);

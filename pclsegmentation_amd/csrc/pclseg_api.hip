@@ -176,14 +176,17 @@ void pack_bias(const SubOp& su, const std::vector<double>& shift, float* bdst) {
   for (int i = 0; i < su.nctp * 16; ++i) bdst[su.nctp * 16 + i] = 1.0f;
 }
 
-// ---- split-f16 weights: per-output-channel power-of-two pre-scale ----------------------------
+// ---- split-f16 weights: power-of-two pre-scale per 16-output-channel tile --------------------
 // w = hi + lo with hi = f16(w), lo = f16(w - hi) carries 22 significant bits only while lo is a NORMAL
 // half: |lo| <= 2^-11 |w| drops below 2^-14 (subnormal, absolute step 2^-24) as soon as |w| < 2^-3 —
-// which is every weight of a trained or He-initialised layer with a large fan-in.  Each output
-// channel's folded weights are therefore multiplied by 2^k, k chosen so that the channel's largest
-// magnitude lands in [2^12, 2^13), before the split; the float32 epilogue multiplies the accumulator
-// by 2^-k (one fmaf with the bias: exact, free).  Elements down to 2^-15 of the channel maximum keep
-// 22 bits; below that the ABSOLUTE error is 2^-25, i.e. 2^-37 of the channel's largest weight.
+// which is every weight of a trained or He-initialised layer with a large fan-in.  The folded weights
+// of each tile of 16 output channels (one MFMA A fragment row block: the granularity at which the
+// kernels can undo a scale from a SCALAR register) are therefore multiplied by 2^k, k chosen so that
+// the tile's largest magnitude lands in [2^12, 2^13), before the split; the float32 epilogue multiplies
+// the accumulator by 2^-k (one fmaf with the bias: exact, free).  Elements down to 2^-15 of the tile
+// maximum keep 22 bits; below that the ABSOLUTE error is 2^-25, i.e. 2^-37 of the tile's largest weight.
+// (A per-channel exponent was measured first: its 2^-k quads cost 4 VGPRs per cout tile in every
+// epilogue and 1.2 % of the step — fire6 31.3 -> 34.8 us, fire13 58.5 -> 65.5 us)
 constexpr int kScaleTarget = 12;   // channel max -> [2^12, 2^13): hi <= 8192, far from the f16 limit
 struct ScaleStat { bool nonfinite = false; };
 int scale_exponent(double maxabs) {
@@ -225,15 +228,16 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
   const int cin8 = (op.cin_t + 7) / 8, ck8_full = op.ck16 / 8;
   const int steps_full = f16_steps_full(op, su), nchunks = f16_chunks(op);
   std::vector<int> kexp((size_t)su.nctp * 16, 0);
-  for (int co = 0; co < su.cout; ++co) {
+  for (int ct = 0; ct < su.nctp; ++ct) {
     double m = 0.0;
-    for (int t = 0; t < taps; ++t)
-      for (int ci = 0; ci < op.cin_k; ++ci) {
-        const double w = std::fabs(folded_w(op, su, f, scale, t, ci, co));
-        if (!(w <= m)) m = w;   // (NaN propagates into m)
-      }
+    for (int co = ct * 16; co < std::min(su.cout, ct * 16 + 16); ++co)
+      for (int t = 0; t < taps; ++t)
+        for (int ci = 0; ci < op.cin_k; ++ci) {
+          const double w = std::fabs(folded_w(op, su, f, scale, t, ci, co));
+          if (!(w <= m)) m = w;   // (NaN propagates into m)
+        }
     if (st && !std::isfinite(m)) st->nonfinite = true;
-    kexp[co] = scale_exponent(m);
+    for (int i = 0; i < 16; ++i) kexp[ct * 16 + i] = scale_exponent(m);
   }
   for (int i = 0; i < su.nctp * 16; ++i) inv[i] = (float)std::ldexp(1.0, -kexp[i]);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -263,21 +267,22 @@ void pack_w16(const Op& op, const SubOp& su, const FoldIn& f, const std::vector<
 // 2st and 2st+1: k-slot (g, j) of partial-GEMM step st is channel
 //   c = co_off(half) + (cg*ntw + 2st + (j >> 2))*16 + 4g + (j & 3)      (zero if that tile does not exist).
 // A-fragment lane (r = lane & 15, g = lane >> 4), element j = BN-folded squeeze weight W[c][16qt + r],
-// scaled per squeeze channel q like every split-f16 weight (`inv`: the squeeze's inverse-scale block).
+// scaled per 16-channel tile of q like every split-f16 weight (`inv`: the squeeze's inverse-scale block).
 void pack_fsq(const Op& op, const FoldIn& f, const std::vector<double>& scale, _Float16* dst, float* inv,
               ScaleStat* st = nullptr) {
   const SubOp& sq = op.fsq;
   const int ncg = op.sub[0].nctp / op.ntw, ns = (op.ntw + 1) / 2, nq = sq.nctp;
   const int cx = op.sub[0].cout + op.sub[1].cout;   // channels of the (never materialised) pair output
   std::vector<int> kexp((size_t)nq * 16, 0);
-  for (int q = 0; q < sq.cout; ++q) {
+  for (int qt = 0; qt < nq; ++qt) {
     double m = 0.0;
-    for (int c = 0; c < cx; ++c) {
-      const double w = std::fabs((double)f.kernel[(size_t)c * sq.cout + q] * scale[q]);
-      if (!(w <= m)) m = w;
-    }
+    for (int q = qt * 16; q < std::min(sq.cout, qt * 16 + 16); ++q)
+      for (int c = 0; c < cx; ++c) {
+        const double w = std::fabs((double)f.kernel[(size_t)c * sq.cout + q] * scale[q]);
+        if (!(w <= m)) m = w;
+      }
     if (st && !std::isfinite(m)) st->nonfinite = true;
-    kexp[q] = scale_exponent(m);
+    for (int i = 0; i < 16; ++i) kexp[qt * 16 + i] = scale_exponent(m);
   }
   for (int i = 0; i < nq * 16; ++i) inv[i] = (float)std::ldexp(1.0, -kexp[i]);
   for (int half = 0; half < 2; ++half)

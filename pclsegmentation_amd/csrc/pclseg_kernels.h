@@ -120,13 +120,18 @@ __device__ __forceinline__ void store_quad(float* dst, const f32x4 v, const bool
   else *reinterpret_cast<f32x4*>(dst) = v;
 }
 
-// Accumulator -> pre-activation value.  Split-f16 weights are packed with a per-output-channel scale
-// 2^k (pclseg_api.hip: scale_exponent), so the accumulator holds 2^k times the convolution sum: one fmaf
-// with the channel's 2^-k and its bias undoes it exactly (a power of two never rounds).
-__device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 s, const f32x4 b) {
+// Accumulator -> pre-activation value.  Split-f16 weights are packed with a power-of-two scale 2^k per
+// 16-output-channel tile (pclseg_api.hip: scale_exponent), so the accumulator holds 2^k times the
+// convolution sum: one fmaf with the tile's 2^-k and the bias undoes it exactly (a power of two never
+// rounds).  The tile index is wave-uniform, so 2^-k comes through the scalar cache into an SGPR
+// (constant address space: the parameter blob is never written while a kernel runs) — no vector
+// register, no vector-memory instruction.
+typedef __attribute__((address_space(4))) const float* const_f32_ptr;
+__device__ __forceinline__ float sload(const float* p) { return *(const_f32_ptr)(p); }
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, const float s, const f32x4 b) {
   f32x4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = fmaf(a[e], s[e], b[e]);
+  for (int e = 0; e < 4; ++e) r[e] = fmaf(a[e], s, b[e]);
   return r;
 }
 
@@ -275,11 +280,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
     // HERE, not hoisted above the K loop where it would cost registers for its whole duration
     int p = lane & 15, g = lane >> 4;
     asm volatile("" : "+v"(p), "+v"(g));
-    f32x4 bv[NTW], iv[F16X3 ? NTW : 1];   // bias, and (split-f16) the inverse weight scale of each channel
+    f32x4 bv[NTW];
+    float iv[F16X3 ? NTW : 1];   // (split-f16) inverse weight scale of each cout tile, scalar
 #pragma unroll
     for (int nn = 0; nn < NTW; ++nn) {
       bv[nn] = *reinterpret_cast<const f32x4*>(E.bias + (ct0 + nn) * 16 + g * 4);
-      if constexpr (F16X3) iv[nn] = *reinterpret_cast<const f32x4*>(E.bias + (E.nctp + ct0 + nn) * 16 + g * 4);
+      if constexpr (F16X3) iv[nn] = sload(E.bias + (E.nctp + ct0 + nn) * 16);
     }
     auto pre = [&](const f32x4 acv, const int nn) -> f32x4 {
       if constexpr (F16X3) return fma4(acv, iv[nn], bv[nn]); else return acv + bv[nn];
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       // (each parity's sub-conv has its own [bias | inverse scale] block, pclseg_graph.h: sub_bias_floats)
       const float* ubp = a.up_bias + (parity * 2 * a.up_nctp + ct) * 16 + g * 4;
       const f32x4 ub = *reinterpret_cast<const f32x4*>(ubp);
-      const f32x4 ui = *reinterpret_cast<const f32x4*>(ubp + a.up_nctp * 16);
+      const float ui = sload(a.up_bias + (parity * 2 * a.up_nctp + a.up_nctp + ct) * 16);
       {
         const _Float16* in16 = reinterpret_cast<const _Float16*>(a.in) + (size_t)n * a.H * a.up_Win * (size_t)(2 * C);
         const int nunits = a.PH * SC * UPP;
@@ -796,11 +802,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           // wave's cout tiles 2st and 2st+1: lane (p, g) contributes k = (g, j): j < 4 -> channel
           // 4g+j of tile 2st, j >= 4 -> channel 4g+j-4 of tile 2st+1 (zero if NTW is odd and it is missing)
           constexpr int NS = (NTW + 1) / 2;
-          f32x4 bv[NTW], iv[NTW];
+          f32x4 bv[NTW];
+          float iv[NTW];
 #pragma unroll
           for (int nn = 0; nn < NTW; ++nn) {
             bv[nn] = *reinterpret_cast<const f32x4*>(K.bias + (ct0 + nn) * 16 + g * 4);
-            iv[nn] = *reinterpret_cast<const f32x4*>(K.bias + (K.nctp + ct0 + nn) * 16 + g * 4);
+            iv[nn] = sload(K.bias + (K.nctp + ct0 + nn) * 16);
           }
           const int cg = ct0 / NTW;   // this wave's cout group within the half
 #pragma unroll
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
 #pragma unroll
           for (int w = 1; w < WN; ++w)
             sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * QS + qq * 4));
-          sum = fma4(sum, *reinterpret_cast<const f32x4*>(a.fsq_bias + Q + qq * 4), *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4));
+          sum = fma4(sum, a.fsq_bias[Q + ((qq * 4) & ~15)], *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4));
 #pragma unroll
           for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.0f);
           const int seg = wmi * MTW + (pl >> 4), pp = pl & 15;
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
         const int co = (ct0 + nn) * 16 + g * 4;
         if (pvalid[m] && co < S.Cout) {
           const size_t px = (size_t)(pix0 + m * 16 + p);
-          v = act4(fma4(v, *reinterpret_cast<const f32x4*>(S.bias + S.nctp * 16 + co), *reinterpret_cast<const f32x4*>(S.bias + co)), S.act);
+          v = act4(fma4(v, sload(S.bias + (S.nctp + ct0 + nn) * 16), *reinterpret_cast<const f32x4*>(S.bias + co)), S.act);
           if constexpr (RES) if (a.res1) {
             const f32x4 r = *reinterpret_cast<const f32x4*>(a.res1 + px * a.res1_C + S.co_off + co);
             v = a.res1_mul ? v * r : v + r;
@@ -1081,7 +1088,7 @@ __global__ __launch_bounds__(kConvThreads, (SPLITK && MTW * NTW == 8) ? 3 : 4) v
   for (int nn = 0; nn < NTW; ++nn) {
     const int co = (ct0 + nn) * 16 + g * 4;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(S.bias + co);
-    const f32x4 iv = *reinterpret_cast<const f32x4*>(S.bias + S.nctp * 16 + co);
+    const float iv = sload(S.bias + (S.nctp + ct0 + nn) * 16);
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
       if (pvalid[m] && co < S.Cout) {
@@ -1192,7 +1199,7 @@ __global__ __launch_bounds__(kConvThreads) void pool_squeeze_kernel(const ConvAr
     for (int nn = 0; nn < NTW; ++nn) {
       const int co = nn * 16 + g * 4;
       if (co >= S.Cout) continue;
-      const f32x4 v = act4(fma4(acc[nn], *reinterpret_cast<const f32x4*>(S.bias + S.nctp * 16 + co), *reinterpret_cast<const f32x4*>(S.bias + co)), S.act);
+      const f32x4 v = act4(fma4(acc[nn], sload(S.bias + (S.nctp + nn) * 16), *reinterpret_cast<const f32x4*>(S.bias + co)), S.act);
       if (a.out_s16) {
         f16x4 hi, lo;
         split4(v, hi, lo);
@@ -1497,7 +1504,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
       for (int nn = 0; nn < SQ; ++nn) {
         const int co = nn * 16 + g * 4;
         if (co >= a.sq_C) continue;
-        f32x4 v = fma4(acc[nn], *reinterpret_cast<const f32x4*>(a.sq_bias + SQ * 16 + co), *reinterpret_cast<const f32x4*>(a.sq_bias + co));
+        f32x4 v = fma4(acc[nn], sload(a.sq_bias + (SQ + nn) * 16), *reinterpret_cast<const f32x4*>(a.sq_bias + co));
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
         if (a.sq_s16) {

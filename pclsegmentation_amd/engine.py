@@ -92,6 +92,15 @@ def load_library():
                                      ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
   lib.pclseg_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), i32]
   lib.pclseg_finalize.argtypes = [vp]
+  if "PCLSEG_LIB" in os.environ:   # A/B against an older build: entry points it lacks fail at the call, not at load
+    class _Missing:
+      def __init__(self, name):
+        self.name, self.argtypes, self.restype = name, None, None
+      def __call__(self, *a):
+        raise RuntimeError("%s is not exported by %s" % (self.name, LIB_PATH))
+    for name in EXPORTS:
+      if not hasattr(lib, name):
+        setattr(lib, name, _Missing(name))
   lib.pclseg_packed_size.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
   lib.pclseg_export_packed.argtypes = [vp, vp, ctypes.c_size_t, i32]
   lib.pclseg_import_packed.argtypes = [vp, vp, ctypes.c_size_t, i32]

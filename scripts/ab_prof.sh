@@ -6,7 +6,7 @@ i=0
 for cfg in "$@"; do
   i=$((i+1))
   rm -rf gpurun_out/ab_$i
-  ( export PCLSEG_LANES=1 $cfg; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ab_$i -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-secondary > /dev/null 2>&1 )
+  ( export PCLSEG_LANES=1; [ -n "$cfg" ] && export $cfg; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ab_$i -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-secondary > /dev/null 2>&1 )
   f=$(find gpurun_out/ab_$i -name '*kernel_trace.csv' | head -1)
   python3 profiles/per_op_breakdown.py $f > gpurun_out/ab_$i.txt
 done
