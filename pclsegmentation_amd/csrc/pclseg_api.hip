@@ -428,18 +428,20 @@ struct StampDump {
   unsigned blocks = 0;
   hipStream_t s;
   std::string name;
-  StampDump(const Op& op, ConvArgs* a, dim3 grid, hipStream_t s_) : s(s_) {
+  const char* const* labels = nullptr;
+  StampDump(const std::string& opname, unsigned long long** field, dim3 grid, hipStream_t s_, const char* const* labels_ = nullptr)
+      : s(s_), labels(labels_) {
     static const char* want = getenv("PCLSEG_STAMP");
     static unsigned long long* dbuf = nullptr;
     static int count = 0;
-    a->stamps = nullptr;
-    if (!want || op.name().find(want) == std::string::npos || grid.x > 16384) return;
+    *field = nullptr;
+    if (!want || opname.find(want) == std::string::npos || grid.x > 16384) return;
     if (!dbuf) (void)hipMalloc((void**)&dbuf, (size_t)16384 * 8 * 8);
     if (++count != 20) return;
     (void)hipMemsetAsync(dbuf, 0, (size_t)grid.x * 64, s);
-    a->stamps = buf = dbuf;
+    *field = buf = dbuf;
     blocks = grid.x;
-    name = op.name();
+    name = opname;
   }
   ~StampDump() {
     if (!buf) return;
@@ -456,7 +458,7 @@ struct StampDump {
     double tot = 0;
     for (int i = 1; i < 8; ++i) tot += sum[i] / blocks;
     fprintf(stderr, "STAMPS %s: %u blocks, %.0f cycles per block\n", name.c_str(), blocks, tot);
-    for (int i = 1; i < 8; ++i) fprintf(stderr, "  %-26s %8.0f cycles  %5.1f %%\n", nm[i], sum[i] / blocks, 100.0 * sum[i] / blocks / tot);
+    for (int i = 1; i < 8; ++i) fprintf(stderr, "  %-26s %8.0f cycles  %5.1f %%\n", (labels ? labels : nm)[i], sum[i] / blocks, 100.0 * sum[i] / blocks / tot);
   }
 };
 #endif
@@ -591,7 +593,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   }
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
 #ifdef PCLSEG_WITH_STAMPS
-  StampDump stamp_dump(op, &a, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split
+  StampDump stamp_dump(op.name(), &a.stamps, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split
 #endif
   const int epi = a.skx ? (a.res1 || a.res2 ? 4 : 3) : a.res2 ? 2 : a.res1 ? 1 : 0;
   if (op.up_fused) {   // `a.in` is the half-width squeeze tensor; Win is the up-convolved width
@@ -667,6 +669,39 @@ hipError_t launch_pool_squeeze(const Op& op, int N, int H, int Win, ConvArgs a, 
     case 3: return launch_pool_squeeze_n<3>(grid, lds, s, a);
     default: return launch_pool_squeeze_n<4>(grid, lds, s, a);
   }
+}
+
+// fire13's merged expand pair + conv14 + head (Op::head_fused); W = full output width.
+hipError_t launch_fire_head(const Op& op, FireHeadArgs f, int N, int H, int W, const _Float16* w16, const float* bias,
+                            hipStream_t s) {
+  if (!w16 || !op.up_fused || op.cin_t != 16 || op.sub[0].nctp != 2 || op.sub[1].nctp != 2 || op.up[0].nctp != 1 ||
+      op.hd.nctp < 1 || op.hd.nctp > 2 || (W & 15) || op.up[1].b_off != op.up[0].b_off + 32)
+    return hipErrorInvalidValue;
+  f.N = N; f.H = H; f.W = W;
+  f.tilesH = (H + kFhTH - 1) / kFhTH;
+  f.tilesW = W / kFhTW;
+  f.NC = op.hd.cout;
+  f.up_w16[0] = w16 + op.up[0].w16_off;
+  f.up_w16[1] = w16 + op.up[1].w16_off;
+  f.up_bias = bias + op.up[0].b_off;
+  f.e1_w16 = w16 + op.sub[0].w16_off; f.e1_bias = bias + op.sub[0].b_off;
+  f.e3_w16 = w16 + op.sub[1].w16_off; f.e3_bias = bias + op.sub[1].b_off;
+  f.skw = bias + op.sk.b_off;
+  f.hd_w16 = w16 + op.hd.w16_off; f.hd_bias = bias + op.hd.b_off;
+  const dim3 grid((unsigned)(N * f.tilesH * f.tilesW));
+#ifdef PCLSEG_WITH_STAMPS
+  static const char* fh_labels[8] = {"entry", "source patch + barrier", "up-conv + barrier", "expand3x3 K", "expand1x1 K",
+                                     "F epilogue + barrier", "conv14 K", "head epilogue"};
+  StampDump stamp_dump(op.name() + "+head", &f.stamps, grid, s, fh_labels);
+#endif
+  if (op.hd.nctp == 1) {
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&fire_head_kernel<1>), kFhLds)) return e;
+    hipLaunchKernelGGL((fire_head_kernel<1>), grid, dim3(256), kFhLds, s, f);
+  } else {
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&fire_head_kernel<2>), kFhLds)) return e;
+    hipLaunchKernelGGL((fire_head_kernel<2>), grid, dim3(256), kFhLds, s, f);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_cam(CamArgs c, int N, int H, int W, int C, hipStream_t s) {
@@ -758,6 +793,20 @@ int run_ops(pclseg_handle* h, int lane, int cnt, const uint8_t* mask, int32_t* p
       c.w1 = h->d_bias + op.sub[0].b_off; c.b1 = c.w1 + (size_t)C * R;
       c.w2 = h->d_bias + op.sub[1].b_off; c.b2 = c.w2 + (size_t)R * C;
       HIP_TRY(h, launch_cam(c, cnt, ti.H, ti.W, C, stream));
+      continue;
+    }
+    if (op.head_fused) {   // fire13 + conv14 + head: `in` is fire13/squeeze at half width
+      if (exact || ti.fmt != FMT_S16) return fail(h, PCLSEG_ERR_STATE, "internal: fused head in an exact-f32 sweep");
+      FireHeadArgs f;
+      memset(&f, 0, sizeof(f));
+      f.sq = reinterpret_cast<const _Float16*>(in);
+      f.x8 = arena + g.tensors[op.sk_in].offset;
+      f.mask = mask; f.preds = preds; f.probs = probs; f.logits = logits;
+      f.none_index = g.desc.none_index;
+      f.range_flag = h->d_range;
+      const hipError_t le = launch_fire_head(op, f, cnt, ti.H, 2 * ti.W, h->d_w16, h->d_bias, stream);
+      if (le != hipSuccess)
+        return fail(h, PCLSEG_ERR_HIP, fmt("launch of '%s' + head failed (%s)", op.name().c_str(), hipGetErrorString(le)));
       continue;
     }
     ConvArgs a;
@@ -1260,7 +1309,8 @@ uint64_t plan_hash(const Graph& g) {
   mix(PCLSEG_VERSION);
   for (const Op& op : g.ops) {
     mix(op.kind); mix(op.ntw); mix(op.wn); mix(op.mtw); mix(op.nw); mix(op.ck16); mix(op.ck32);
-    mix(op.pair); mix(op.fsq_fused); mix(op.up_fused); mix(op.pool_fused);
+    mix(op.pair); mix(op.fsq_fused); mix(op.up_fused); mix(op.pool_fused); mix(op.head_fused);
+    if (op.head_fused) { mix(op.hd.w16_off); mix(op.hd.b_off); }
     for (int i = 0; i < op.nsub; ++i) { mix(op.sub[i].w16_off); mix(op.sub[i].w32_off); mix(op.sub[i].b_off); mix(op.sub[i].nctp); }
     if (op.fsq_fused) { mix(op.fsq.w16_off); mix(op.fsq.b_off); }
     if (op.up_fused) for (int i = 0; i < 2; ++i) { mix(op.up[i].w16_off); mix(op.up[i].b_off); }
@@ -1507,6 +1557,22 @@ int pclseg_finalize(pclseg_handle* h) {
       } else {
         pack_fsq(op, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
       }
+    }
+    if (op.head_fused) {   // conv14 as one 64-channel chunk (fire_head_kernel reads (tap, 8-channel group) pairs 4 st + g)
+      if (!want16) return fail(h, PCLSEG_ERR_STATE, "internal: fused head in an exact-f32 plan");
+      const SubOp& su = op.hd;
+      FoldIn f;
+      f.kernel = W(su.name + "/kernel"); f.bias = W(su.name + "/bias");
+      if (!f.kernel || !f.bias)
+        return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", su.name.c_str()));
+      Op as_head;
+      as_head.kind = OP_HEAD;
+      as_head.cin_t = as_head.cin_k = 64;
+      as_head.ck16 = 64;
+      std::vector<double> scale, shift;
+      fold_bn(su, f, &scale, &shift);
+      pack_bias(su, shift, bias.data() + su.b_off);
+      pack_w16(as_head, su, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
     }
     if (op.up_fused) {
       if (!want16) return fail(h, PCLSEG_ERR_STATE, "internal: fused up-convolution in an exact-f32 plan");

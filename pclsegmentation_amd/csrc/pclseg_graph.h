@@ -106,6 +106,11 @@ struct Op {
   // in the epilogue; `sk` names its Keras tensors, sk.b_off locates [8][C] weights + [C] bias
   int sk_in = -1;
   SubOp sk;
+  // fire13 -> conv14 -> head in one kernel (fire_head_kernel): this expand pair (up_fused, fused skip branch)
+  // also runs the segmentation head that is its only reader; `hd` is the head's 3x3 conv, the pair's own
+  // output tensor is never materialised and the op writes predictions / probabilities / logits
+  bool head_fused = false;
+  SubOp hd;
   std::string name() const { return sub[0].name; }
 };
 
@@ -808,6 +813,29 @@ inline void fuse_upconvs(Graph* g) {
   if (changed) recompute_lifetimes(g);
 }
 
+// SqueezeSegV2's tail (nets/SqueezeSegV2.py:318-325): fire13's expand pair + skip branch feeds only conv14,
+// whose logits feed only the head.  With the up-convolution already inside the pair (fuse_upconvs) the three
+// run as ONE kernel that keeps fire13's 64-channel output in LDS (fire_head_kernel): 16 + 32 + 32 -> 64
+// channels, up to 32 classes.
+inline void fuse_head(Graph* g) {
+  static const int on = getenv("PCLSEG_FUSE_HEAD") ? atoi(getenv("PCLSEG_FUSE_HEAD")) : 1;
+  const size_t n = g->ops.size();
+  if (!on || n < 2) return;
+  Op& e = g->ops[n - 2];
+  const Op& hd = g->ops[n - 1];
+  if (hd.kind != OP_HEAD || e.kind != OP_CONV || hd.in != e.out || !e.pair || !e.up_fused || e.fsq_fused || e.sk_in < 0 ||
+      e.res1 >= 0 || e.res2 >= 0 || e.nsub != 2) return;
+  if (e.cin_t != 16 || e.sub[0].cout != 32 || e.sub[1].cout != 32 || e.sk.cout != 64 || hd.cin_t != 64 ||
+      hd.sub[0].cout > 32 || hd.pkh != 3 || hd.pkw != 3) return;
+  for (size_t i = 0; i + 2 < n; ++i)   // fire13's output must have no other reader
+    if (g->ops[i].in == e.out || g->ops[i].res1 == e.out || g->ops[i].res2 == e.out) return;
+  e.head_fused = true;
+  e.hd = hd.sub[0];
+  e.out = -1;
+  g->ops.pop_back();
+  recompute_lifetimes(g);
+}
+
 inline int resolve_micro_batch(const pclseg_desc& d) {
   if (d.micro_batch > 0) return d.micro_batch;
   const int64_t px = (int64_t)d.height * d.width;
@@ -857,7 +885,7 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
   if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) build_squeezesegv2(g);
   else build_darknet(g, d->arch == PCLSEG_ARCH_DARKNET21 ? 21 : 53);
   assign_formats(g);
-  if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) fuse_upconvs(g);
+  if (d->arch == PCLSEG_ARCH_SQUEEZESEGV2) { fuse_upconvs(g); fuse_head(g); }
   // packed-parameter geometry: exact-f32 fragments, split-f16 fragments, biases
   for (Op& op : g->ops) {
     if (op.kind == OP_POOL) continue;
@@ -891,6 +919,13 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
       g->packed16_halfs += fsq_w16_halfs(op);
       op.fsq.b_off = g->packed_bias_floats;
       g->packed_bias_floats += sub_bias_floats(op.fsq);
+    }
+    if (op.head_fused) {   // conv14's fragments, packed with ONE 64-channel chunk: 18 K-steps x nctp tiles
+      op.hd.nctp = (op.hd.cout + 15) / 16;
+      op.hd.w16_off = g->packed16_halfs;
+      g->packed16_halfs += (int64_t)18 * op.hd.nctp * 1024;
+      op.hd.b_off = g->packed_bias_floats;
+      g->packed_bias_floats += sub_bias_floats(op.hd);
     }
     if (op.up_fused) {   // the transposed conv's two parities, packed like any 2-tap sub-conv of this op
       for (int i = 0; i < 2; ++i) {

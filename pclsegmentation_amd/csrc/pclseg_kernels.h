@@ -177,6 +177,80 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Segmentation head of one pixel (reference: nets/SegmentationNetwork.py:58-69): [softmax ->] argmax ->
+// mask.  lv[nn] holds this lane's 4 logits of cout tile nn (channels nn*16 + 4g .. +3); the NTW tiles
+// hold all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.  A NaN or +inf logit
+// makes every softmax probability of the pixel NaN, and tf.argmax over all-NaN probabilities yields
+// index 0: such pixels get class 0, never an out-of-range id.  Must be called from convergent code.
+template <int NTW>
+__device__ __forceinline__ void head_finish(const f32x4 (&lv)[NTW], const bool valid, const size_t pix, const int g,
+                                            const int NC, const uint8_t mask_px, int32_t* preds, float* probs,
+                                            float* logits, const int none_index) {
+  float val[NTW * 4];
+  float best = -INFINITY;
+  int bi = 0;
+  bool bad = false;
+#pragma unroll
+  for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = nn * 16 + g * 4 + i;
+      const float v = lv[nn][i];
+      val[nn * 4 + i] = v;
+      if (co < NC) {
+        if (logits && valid) logits[pix * NC + co] = v;
+        bad = bad || !(v < INFINITY);   // NaN or +inf
+        if (v > best) { best = v; bi = co; }
+      }
+    }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float ov = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  {
+    int b = bad ? 1 : 0;
+    b |= __shfl_xor(b, 16);
+    b |= __shfl_xor(b, 32);
+    bad = b != 0;
+  }
+  if (probs) {
+    // softmax materialised: exp(x - max) / sum, and the argmax is taken over the
+    // probabilities exactly as the reference does (lowest index wins ties).
+    float sum = 0.f;
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nn * 16 + g * 4 + i < NC) sum += expf(val[nn * 4 + i] - best);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    float pbest = -1.f;
+    int pbi = 0;
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = nn * 16 + g * 4 + i;
+        if (co < NC) {
+          const float pr = bad ? NAN : expf(val[nn * 4 + i] - best) / sum;
+          if (valid) probs[pix * NC + co] = pr;
+          if (pr > pbest) { pbest = pr; pbi = co; }
+        }
+      }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float ov = __shfl_xor(pbest, off);
+      const int oi = __shfl_xor(pbi, off);
+      if (ov > pbest || (ov == pbest && oi < pbi)) { pbest = ov; pbi = oi; }
+    }
+    bi = pbi;
+  }
+  if (bad) bi = 0;
+  if (g == 0 && valid) preds[pix] = mask_px ? bi : none_index;
+}
+
 // Block = 4 waves arranged WM x WN (WM = 4/WN): wave (wm, wn) owns MTW (2 or 4) pixel segments
 // {wm*MTW ..} and NTW 16-cout tiles {wn*NTW ..}.  WN = 2 halves the weight fragments each
 // wave streams from L2 (the block shares one 64-cout group), WN = 1 keeps all couts of a pixel in
@@ -386,75 +460,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
         const bool valid = (oh < a.H) && (j < a.Wconv);
         const int ow = j * a.ow_mul + E.ow_off;
         const size_t pix = ((size_t)n * a.H + oh) * a.Wout + ow;
-        // segmentation head (reference: nets/SegmentationNetwork.py:58-69).  The NT tiles hold
-        // all NUM_CLASS logits of a pixel across the 4 lanes {p, p+16, p+32, p+48}.
-        // A NaN or +inf logit makes every softmax probability of the pixel NaN, and tf.argmax
-        // over all-NaN probabilities yields index 0: such pixels get class 0, never an
-        // out-of-range id.
-        const int NC = E.Cout;
-        float val[NTW * 4];
-        float best = -INFINITY;
-        int bi = 0;
-        bool bad = false;
+        f32x4 lv[NTW];
 #pragma unroll
-        for (int nn = 0; nn < NTW; ++nn)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int co = nn * 16 + g * 4 + i;
-            const float v = pre(ac[m][nn], nn)[i];
-            val[nn * 4 + i] = v;
-            if (co < NC) {
-              if (a.logits && valid) a.logits[pix * NC + co] = v;
-              bad = bad || !(v < INFINITY);   // NaN or +inf
-              if (v > best) { best = v; bi = co; }
-            }
-          }
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-          const float ov = __shfl_xor(best, off);
-          const int oi = __shfl_xor(bi, off);
-          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        {
-          int b = bad ? 1 : 0;
-          b |= __shfl_xor(b, 16);
-          b |= __shfl_xor(b, 32);
-          bad = b != 0;
-        }
-        if (a.probs) {
-          // softmax materialised: exp(x - max) / sum, and the argmax is taken over the
-          // probabilities exactly as the reference does (lowest index wins ties).
-          float sum = 0.f;
-#pragma unroll
-          for (int nn = 0; nn < NTW; ++nn)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (nn * 16 + g * 4 + i < NC) sum += expf(val[nn * 4 + i] - best);
-          sum += __shfl_xor(sum, 16);
-          sum += __shfl_xor(sum, 32);
-          float pbest = -1.f;
-          int pbi = 0;
-#pragma unroll
-          for (int nn = 0; nn < NTW; ++nn)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int co = nn * 16 + g * 4 + i;
-              if (co < NC) {
-                const float pr = bad ? NAN : expf(val[nn * 4 + i] - best) / sum;
-                if (valid) a.probs[pix * NC + co] = pr;
-                if (pr > pbest) { pbest = pr; pbi = co; }
-              }
-            }
-#pragma unroll
-          for (int off = 16; off <= 32; off <<= 1) {
-            const float ov = __shfl_xor(pbest, off);
-            const int oi = __shfl_xor(pbi, off);
-            if (ov > pbest || (ov == pbest && oi < pbi)) { pbest = ov; pbi = oi; }
-          }
-          bi = pbi;
-        }
-        if (bad) bi = 0;
-        if (g == 0 && valid) a.preds[pix] = a.mask[pix] ? bi : a.none_index;
+        for (int nn = 0; nn < NTW; ++nn) lv[nn] = pre(ac[m][nn], nn);
+        head_finish<NTW>(lv, valid, pix, g, E.Cout, valid ? a.mask[pix] : (uint8_t)0, a.preds, a.probs, a.logits, a.none_index);
       }
     }
   };
@@ -922,6 +931,408 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
     stamp(7);
     if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
   }
+}
+
+// ---- fire13 -> conv14 -> head in one kernel (SqueezeSegV2's tail, nets/SqueezeSegV2.py:276-282,318-325)
+//   fire13/upconv (Conv2DTranspose (1,4)/(1,2) + ReLU)  ->  expand1x1 || expand3x3 (+BN+ReLU)
+//   -> + bn1_skip(conv1_skip(input))  ->  [dropout: identity]  ->  conv14 3x3 -> [softmax] -> argmax -> mask
+// fire13's 64-channel full-resolution output (33.5 MB per scan written, 35.5 MB re-read by the head: 16 %
+// of all HBM-side traffic of the network and two of its three longest launches) never leaves the CU: a
+// 4-wave block owns an 8 x 16 pixel tile of PREDICTIONS and keeps, in LDS,
+//   U  the up-convolved squeeze (16 ch) on the tile + 2-pixel halo, 12 x 20 px, split-f16 [hi 16|lo 16|pad]
+//   F  fire13's output (64 ch, after the skip add) on the tile + 1-pixel halo, 10 x 18 px = 12 segments of
+//      16 pixels (flattened), split-f16 [hi 64|lo 64|pad]; pixels outside the image are ZERO (conv14's
+//      padding), not fire13 evaluated on padding
+// 72 KB per block: two blocks per CU, so one block's staging / epilogues overlap the other's K loops.
+//   phase 0  half-width squeeze patch (12 x 12 source pixels) -> LDS (aliases F), skip weights -> LDS
+//   phase 1  up-convolution: wave <-> (output parity, half of the 16-pixel units), K = 2 taps x 16
+//   phase 2  expand pair on the 12 F segments (3 per wave, weight fragments fetched once per wave):
+//            3x3 half 5 K-steps + 1x1 half 1 K-step, bias/ReLU, skip branch from the 8-channel network
+//            input (32 B per pixel from L2), zero outside the image, split -> F
+//   phase 3  conv14 on the 8 tile rows (2 per wave): 18 K-steps over (tap, 8-channel group) pairs of F,
+//            packed head fragments streamed through a 2-deep ring, then head_finish
+// The halo costs 1.41x fire13's matrix work (180 px computed for 128) - fire13 is 1/4 of the block's MFMAs.
+// Only 9 MB per scan cross the memory system (squeeze tensor, raw input, mask, predictions).
+struct FireHeadArgs {
+  const _Float16* sq;      // fire13/squeeze [N,H,W/2][hi 16 | lo 16]
+  const float* x8;         // network input [N,H,W,8] (skip branch)
+  const uint8_t* mask;     // [N,H,W]
+  int32_t* preds;
+  float* probs;            // optional
+  float* logits;           // optional
+  int N, H, W, tilesH, tilesW, NC, none_index;
+  const _Float16* up_w16[2];   // transposed conv, one 1-step fragment set per output parity
+  const float* up_bias;        // [parity][bias 16 | inv 16]
+  const _Float16* e1_w16;      // expand1x1 (1 K-step used), e3: expand3x3 (5 K-steps); 2 cout tiles each
+  const _Float16* e3_w16;
+  const float* e1_bias;        // [bias 32 | inv 32]
+  const float* e3_bias;
+  const float* skw;            // [8][64] folded conv1_skip weights + [64] bias
+  const _Float16* hd_w16;      // conv14: 18 K-steps x NCT tiles (packed with a 64-channel chunk)
+  const float* hd_bias;        // [bias NCT*16 | inv NCT*16]
+  unsigned* range_flag;
+#ifdef PCLSEG_WITH_STAMPS
+  unsigned long long* stamps;
+#endif
+};
+
+constexpr int kFhTH = 8, kFhTW = 16;                 // prediction tile
+constexpr int kFhFW = kFhTW + 2, kFhFH = kFhTH + 2;   // F region 10 x 18
+constexpr int kFhUW = kFhTW + 4, kFhUH = kFhTH + 4;   // U region 12 x 20
+constexpr int kFhSW = kFhUW / 2 + 2;                  // source columns 12
+constexpr int kFhCSU = 2 * 16 + kPadF16;              // halfs per U / source pixel
+constexpr int kFhCSF = 2 * 64 + kPadF16;              // halfs per F pixel
+constexpr int kFhFSeg = (kFhFH * kFhFW + 15) / 16;    // 12 segments
+constexpr int kFhLdsF = kFhFSeg * 16 * kFhCSF * 2;    // bytes
+constexpr int kFhLdsU = kFhUH * kFhUW * kFhCSU * 2;
+constexpr int kFhLds = kFhLdsF + kFhLdsU + 9 * 64 * 4;
+static_assert(kFhUH * kFhSW * kFhCSU * 2 <= kFhLdsF, "the source patch aliases F");
+static_assert(kFhFSeg == 12, "3 F segments per wave");
+
+// Workgroup barrier that leaves this wave's global loads in flight: __syncthreads() drains vmcnt too, which
+// would turn every prefetch issued before it into a stall at it.  LDS traffic is ordered by lgkmcnt.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// What was measured on the way (s_memtime stamps per phase, one lane, 4 scans):
+//   v1  weights streamed per wave through a 2-deep ring, operands fetched where used, __syncthreads():
+//       136 us = the two separate launches; 32 k cycles per block for 5.4 k cycles of matrix work
+//   v2  this kernel: every operand requested at entry, barriers that do not drain vmcnt, expand fragments
+//       resident, conv14's K-steps dealt to the waves: 121 us
+//   v3  persistent blocks (2 per CU) with the next tile's patch requested a phase ahead: 161 us, and 3-lane
+//       throughput 5700 instead of 6390 scans/s — resident blocks hold 144 KB of LDS per CU for the whole
+//       launch and shut the other lanes' kernels out; the prefetched operands spilled to scratch
+//   v4  8 waves per block at 128 registers (4 waves per SIMD): 206 us — register spills in the F epilogue
+// The block is bound by instruction issue, not by any pipe: ~2000 vector + ~1100 scalar + ~250 LDS
+// instructions per wave and tile beside 351 MFMAs, at two waves per SIMD.
+template <int NCT>
+__global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* F = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* S = F;                                                       // source patch (dead before F is written)
+  _Float16* U = reinterpret_cast<_Float16*>(smem_raw + kFhLdsF);
+  float* skw_lds = reinterpret_cast<float*>(smem_raw + kFhLdsF + kFhLdsU);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const unsigned lane8 = (unsigned)lane * 8u;   // fragment addresses: base in SGPRs + this shared lane offset
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int twi = tile % a.tilesW;
+  tile /= a.tilesW;
+  const int thi = tile % a.tilesH;
+  const int n = tile / a.tilesH;
+  const int h0 = thi * kFhTH, w0 = twi * kFhTW;
+  const int W2 = a.W >> 1;
+  float vmax = 0.f;
+#ifdef PCLSEG_WITH_STAMPS
+  auto stamp = [&](int i) { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime(); };
+#else
+  auto stamp = [](int) {};
+#endif
+  stamp(0);
+
+  // ------------------------------------------------ entry: every long-latency operand is requested NOW
+  // Two blocks share a CU and each is a chain of short phases; a phase that began with a memory round
+  // trip would expose it.
+  const int parity = wave & 1;
+  // (1) the half-width squeeze patch, 12 x 12 source pixels x 4 sixteen-byte units = 576 units
+  constexpr int kSrcUnits = kFhUH * kFhSW * 4, kSrcPer = (kSrcUnits + 255) / 256;
+  f16x8 sv[kSrcPer];
+  {
+    const _Float16* sqn = a.sq + (size_t)n * a.H * W2 * 32;
+    const int j0 = (w0 >> 1) - 2;
+#pragma unroll
+    for (int k = 0; k < kSrcPer; ++k) {
+      const int i = tid + k * 256;
+      const int px = (i < kSrcUnits ? i : 0) >> 2, un = i & 3;
+      const int r = px / kFhSW, c = px - r * kFhSW;
+      const int h = h0 - 2 + r, col = j0 + c;
+      const bool ok = i < kSrcUnits && h >= 0 && h < a.H && col >= 0 && col < W2;
+      sv[k] = *reinterpret_cast<const f16x8*>(ok ? sqn + ((size_t)h * W2 + col) * 32 + un * 8 : sqn);
+      if (!ok) sv[k] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  // (2) this wave's up-conv fragments (one K-step, one cout tile) of its output parity
+  const f16x8 uwh = *reinterpret_cast<const f16x8*>(a.up_w16[parity] + lane8);
+  const f16x8 uwl = *reinterpret_cast<const f16x8*>(a.up_w16[parity] + 512 + lane8);
+  const f32x4 ub = *reinterpret_cast<const f32x4*>(a.up_bias + parity * 32 + g * 4);
+  const float ui = sload(a.up_bias + parity * 32 + 16);
+  // (3) skip-branch weights -> LDS (through a register); the raw input's addresses of this wave's 3 F segments
+  f32x4 skq = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid < 9 * 64 / 4) skq = *reinterpret_cast<const f32x4*>(a.skw + tid * 4);
+  int uoff[3];
+  bool fvalid[3], fimg[3];
+  const float* sxp[3];
+  {
+    const float* x8n = a.x8 + (size_t)n * a.H * a.W * 8;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int l = (wave * 3 + m) * 16 + p;
+      fvalid[m] = l < kFhFH * kFhFW;
+      const int lc = fvalid[m] ? l : kFhFH * kFhFW - 1;
+      const int r = lc / kFhFW, c = lc - r * kFhFW;
+      uoff[m] = (r * kFhUW + c) * kFhCSU;
+      const int h = h0 - 1 + r, w = w0 - 1 + c;
+      fimg[m] = h >= 0 && h < a.H && w >= 0 && w < a.W;
+      sxp[m] = fimg[m] ? x8n + ((size_t)h * a.W + w) * 8 : x8n;
+    }
+  }
+  // (4) the expand3x3 fragments: 5 K-steps x 2 cout tiles, hi + lo = 80 registers (the 1x1 half's 16, the
+  //     skip input's 24 and the head bias follow as the 3x3 steps retire their fragments: a register
+  //     budget of 256 per wave does not hold everything at once)
+  f16x8 e3h[5][2], e3l[5][2], e1h[2], e1l[2];
+#pragma unroll
+  for (int st = 0; st < 5; ++st)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      e3h[st][t] = *reinterpret_cast<const f16x8*>(a.e3_w16 + (st * 2 + t) * 1024 + lane8);
+      e3l[st][t] = *reinterpret_cast<const f16x8*>(a.e3_w16 + (st * 2 + t) * 1024 + 512 + lane8);
+    }
+  f32x4 sx0[3], sx1[3];
+  f32x4 hbv[NCT];
+  float hiv[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) hiv[t] = sload(a.hd_bias + (NCT + t) * 16);
+  // (5) this lane's mask bytes (output rows 2 wave, 2 wave + 1, column p)
+  bool ovalid[2];
+  size_t opix[2];
+  uint8_t omask[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int oh = h0 + wave * 2 + m, ow = w0 + p;
+    ovalid[m] = oh < a.H && ow < a.W;
+    opix[m] = ((size_t)n * a.H + oh) * a.W + ow;
+    omask[m] = ovalid[m] ? a.mask[opix[m]] : (uint8_t)0;
+  }
+
+  // ---------------------------------------------------------------- phase 0: patch and skip weights -> LDS
+#pragma unroll
+  for (int k = 0; k < kSrcPer; ++k) {
+    const int i = tid + k * 256;
+    if (i < kSrcUnits) *reinterpret_cast<f16x8*>(S + (i >> 2) * kFhCSU + (i & 3) * 8) = sv[k];
+  }
+  if (tid < 9 * 64 / 4) *reinterpret_cast<f32x4*>(skw_lds + tid * 4) = skq;
+  lds_barrier();
+  stamp(1);
+
+  // ---------------------------------------------------------------- phase 1: up-convolution -> U
+  // output column w = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1); U column pc
+  // is image column w0 - 2 + pc (w0 - 2 is even, so pc has the parity of w)
+  {
+    constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16;
+#pragma nounroll
+    for (int u0 = 0; u0 < UNITS; u0 += 2) {
+      const int u = u0 + (wave >> 1);
+      const int l = u * 16 + p;
+      const bool lv = l < PER;
+      const int lc = lv ? l : PER - 1;
+      const int pr = lc / (kFhUW / 2), k2 = lc - pr * (kFhUW / 2);
+      const int pc = 2 * k2 + parity;
+      const int h = h0 - 2 + pr, w = w0 - 2 + pc;
+      const bool pv = h >= 0 && h < a.H && w >= 0 && w < a.W;
+      const int tap = g >> 1, c8 = g & 1;
+      const _Float16* sp = S + (pr * kFhSW + k2 + parity + tap) * kFhCSU + c8 * 8;
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(sp);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(sp + 16);
+      f32x4 au = (f32x4){0.f, 0.f, 0.f, 0.f};
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwl, xh, au, 0, 0, 0);
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xl, au, 0, 0, 0);
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xh, au, 0, 0, 0);
+      if (lv) {
+        f32x4 v = fma4(au, ui, ub);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
+        vmax = absmax4(vmax, v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        _Float16* d = U + (pr * kFhUW + pc) * kFhCSU + g * 4;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 16) = lo;
+      }
+    }
+  }
+  lds_barrier();   // U complete (and every wave is done reading S: F may be overwritten)
+  stamp(2);
+
+  // ---------------------------------------------------------------- phase 2: expand pair + skip -> F
+  // head fragments of THIS wave's K-steps {wave, wave + 4, ...} (phase 3) are requested as the expand
+  // fragments' registers come free, in flight during the F epilogue
+  constexpr int kHdSteps = 5;   // ceil(18 / 4); step 16 + wave exists for waves 0 and 1 only
+  f16x8 hwh[kHdSteps][NCT], hwl[kHdSteps][NCT];
+  auto load_hw = [&](const int i) {
+    const int st = wave + 4 * i < 18 ? wave + 4 * i : wave;   // (waves 2, 3: the fifth slot is unused)
+    const _Float16* wp = a.hd_w16 + st * (NCT * 1024);         // (scalar)
+#pragma unroll
+    for (int tt = 0; tt < NCT; ++tt) {
+      hwh[i][tt] = *reinterpret_cast<const f16x8*>(wp + tt * 1024 + lane8);
+      hwl[i][tt] = *reinterpret_cast<const f16x8*>(wp + tt * 1024 + 512 + lane8);
+    }
+  };
+  {
+    f32x4 acc[3][4];   // tiles 0,1: expand1x1 (channels 0..31), tiles 2,3: expand3x3 (32..63)
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // expand3x3: K pairs (tap, 8-channel group) = 18 -> 5 steps; lane group g of step s owns pair 4s + g
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      int kidx = 4 * st + g;
+      if (kidx >= 18) kidx = 0;   // padded K: zero weights, any valid address
+      const int tap = kidx >> 1, c8 = kidx & 1;
+      const int ti = (tap * 11) >> 5;   // tap / 3 for tap < 9
+      const int koff = (ti * kFhUW + (tap - 3 * ti)) * kFhCSU + c8 * 8;
+      f16x8 xh[3], xl[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        xh[m] = *reinterpret_cast<const f16x8*>(U + uoff[m] + koff);
+        xl[m] = *reinterpret_cast<const f16x8*>(U + uoff[m] + koff + 16);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[m][2 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e3l[st][t], xh[m], acc[m][2 + t], 0, 0, 0);
+          acc[m][2 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e3h[st][t], xl[m], acc[m][2 + t], 0, 0, 0);
+          acc[m][2 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e3h[st][t], xh[m], acc[m][2 + t], 0, 0, 0);
+        }
+      asm volatile("" ::: "memory");   // (keeps the compiler from hoisting the loads below back to the kernel entry)
+      if (st == 0) {          // the registers of step 0's fragments are free: the 1x1 half's fragments
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          e1h[t] = *reinterpret_cast<const f16x8*>(a.e1_w16 + t * 1024 + lane8);
+          e1l[t] = *reinterpret_cast<const f16x8*>(a.e1_w16 + t * 1024 + 512 + lane8);
+        }
+      } else if (st == 1) {   // the skip branch's raw input of segments 0 and 1
+        sx0[0] = *reinterpret_cast<const f32x4*>(sxp[0]); sx1[0] = *reinterpret_cast<const f32x4*>(sxp[0] + 4);
+        sx0[1] = *reinterpret_cast<const f32x4*>(sxp[1]); sx1[1] = *reinterpret_cast<const f32x4*>(sxp[1] + 4);
+      } else if (st == 2) {   // ... of segment 2, and the head's bias
+        sx0[2] = *reinterpret_cast<const f32x4*>(sxp[2]); sx1[2] = *reinterpret_cast<const f32x4*>(sxp[2] + 4);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) hbv[t] = *reinterpret_cast<const f32x4*>(a.hd_bias + t * 16 + g * 4);
+      }
+    }
+    stamp(3);
+    // expand1x1: the centre tap, 2 channel groups -> 1 step (lane groups 2, 3 carry zero weights)
+    {
+      const int koff = (1 * kFhUW + 1) * kFhCSU + (g & 1) * 8;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(U + uoff[m] + koff);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(U + uoff[m] + koff + 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e1l[t], xh, acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e1h[t], xl, acc[m][t], 0, 0, 0);
+          acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(e1h[t], xh, acc[m][t], 0, 0, 0);
+        }
+      }
+    }
+    stamp(4);
+    asm volatile("" ::: "memory");
+    load_hw(0); load_hw(1); load_hw(2);   // (the last two steps' follow the epilogue: register budget)
+    // bias + ReLU, + skip branch (nets/SqueezeSegV2.py:293,319), zero outside the image, split -> F
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* bb = t < 2 ? a.e1_bias : a.e3_bias;
+      const int tt = t & 1, co = t * 16 + g * 4;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + tt * 16 + g * 4);
+      const float iv = sload(bb + 32 + tt * 16);
+      f32x4 z[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) z[m] = *reinterpret_cast<const f32x4*>(skw_lds + 8 * 64 + co);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // one weight quad at a time (all nine at once cost 36 registers)
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(skw_lds + c * 64 + co);
+        const f32x4 wb = *reinterpret_cast<const f32x4*>(skw_lds + (4 + c) * 64 + co);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[m][e] = fmaf(sx0[m][c], wa[e], z[m][e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[m][e] = fmaf(sx1[m][c], wb[e], z[m][e]);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        f32x4 v = fma4(acc[m][t], iv, bv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        v += z[m];
+        if (!fimg[m]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        vmax = absmax4(vmax, v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        if (fvalid[m]) {
+          _Float16* d = F + ((wave * 3 + m) * 16 + p) * kFhCSF + co;
+          *reinterpret_cast<f16x4*>(d) = hi;
+          *reinterpret_cast<f16x4*>(d + 64) = lo;
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    load_hw(3); load_hw(4);
+  }
+  lds_barrier();
+  stamp(5);
+
+  // ---------------------------------------------------------------- phase 3: conv14, K split over the waves
+  // The 18 K-steps (pair 4 st + g = tap st / 2, channel group 4 (st & 1) + g) are dealt to the 4 waves;
+  // a wave keeps ITS steps' fragments in registers and sweeps all 8 tile rows with them, so conv14's 72 KB
+  // of fragments enter the block once (a wave that owned rows would stream all of them per 2 rows: 288 KB
+  // per block through a 64 B/clk vector L1, more than the matrix work takes).  The four partial sums of a
+  // row meet in LDS and are added in a fixed order (deterministic).
+  {
+    f32x4 acc[8][NCT];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fbase = p * kFhCSF + g * 8;
+#pragma unroll
+    for (int i = 0; i < kHdSteps; ++i) {
+      const int st = wave + 4 * i;
+      if (st < 18) {   // wave-uniform
+        const int tap = st >> 1, ti = (tap * 11) >> 5, tj = tap - 3 * ti;
+        const int koff = fbase + (ti * kFhFW + tj) * kFhCSF + (st & 1) * 32;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const f16x8 xh = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF));
+          const f16x8 xl = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF) + 64);
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) {
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl[i][t], xh, acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xl, acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xh, acc[r][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    stamp(6);
+    // partial sums -> LDS [wave][row][tile][lane] (F and U are dead once every wave is here)
+    f32x4* part = reinterpret_cast<f32x4*>(smem_raw);
+    static_assert(4 * 8 * 2 * 64 * 16 <= kFhLdsF + kFhLdsU, "the partial sums alias F and U");
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) part[((wave * 8 + r) * NCT + t) * 64 + lane] = acc[r][t];
+    lds_barrier();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x4 lv[NCT];
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) {
+        f32x4 sum = part[((0 * 8 + wave * 2 + m) * NCT + t) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += part[((w * 8 + wave * 2 + m) * NCT + t) * 64 + lane];
+        lv[t] = fma4(sum, hiv[t], hbv[t]);
+      }
+      head_finish<NCT>(lv, ovalid[m], opix[m], g, a.NC, omask[m], a.preds, a.probs, a.logits, a.none_index);
+    }
+  }
+  stamp(7);
+  if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
 
 // ---- 1x1 convolutions without LDS (split-f16 mode).
