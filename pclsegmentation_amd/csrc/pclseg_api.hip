@@ -626,6 +626,35 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   if (op.up_fused) return hipErrorInvalidValue;
   if (op.nw == 8) {   // Darknet's wide layers: 128 px x 128 couts, 8 waves (op_geometry)
     if (exact || op.kind == OP_HEAD || op.ntw != 2) return hipErrorInvalidValue;
+    if (op.mtw == 8 && op.wn == 8 && epi <= 2) {
+      // 128 px x 256 couts: the register-capped variant (two blocks per CU).  Tuning build: PCLSEG_DN_VARIANT = 0 the
+      // uncapped kernel (147-226 registers, one block per CU), 1 capped, 2 loader waves (conv_kernel LW; measured: no gain)
+      static const int variant = tune_env("PCLSEG_DN_VARIANT", 1);
+#define PCLSEG_CAP(E_) hipLaunchKernelGGL((conv_kernel<8, 2, 8, false, true, E_, false, 8, 0, 0, 0, true>), grid, dim3(512), lds, s, a)
+      if (variant == 1) {
+        switch (epi) { case 0: PCLSEG_CAP(0); break; case 1: PCLSEG_CAP(1); break; default: PCLSEG_CAP(2); break; }
+        return hipGetLastError();
+      }
+#undef PCLSEG_CAP
+#ifdef PCLSEG_TUNING
+      const int cin8 = (op.cin_t + 7) / 8, ck8_full = op.ck16 / 8;
+      if (variant == 2 && cin8 > ck8_full && epi <= 1 && !a.skx) {
+        const size_t lds2 = 2 * ((lds + 15) & ~(size_t)15);
+        if (lds2 <= 160 * 1024) {
+          if (epi == 0) {
+            auto kfn = conv_kernel<8, 2, 8, false, true, 0, false, 8, 0, 0, 4>;
+            if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds2)) return e;
+            hipLaunchKernelGGL(kfn, grid, dim3(12 * 64), lds2, s, a);
+          } else {
+            auto kfn = conv_kernel<8, 2, 8, false, true, 1, false, 8, 0, 0, 4>;
+            if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds2)) return e;
+            hipLaunchKernelGGL(kfn, grid, dim3(12 * 64), lds2, s, a);
+          }
+          return hipGetLastError();
+        }
+      }
+#endif
+    }
     if (op.mtw == 4 && op.wn == 4) return launch_conv_epi<4, 2, 4, false, true, false, 8>(epi, grid, lds, s, a);
     if (op.mtw == 8 && op.wn == 8) return launch_conv_epi<8, 2, 8, false, true, false, 8>(epi, grid, lds, s, a);
     return hipErrorInvalidValue;
@@ -1363,6 +1392,49 @@ int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out) {
   out->workspace_bytes = g.arena_floats * (int64_t)sizeof(float);
   const bool exact = (desc->flags & PCLSEG_FLAG_EXACT_F32) != 0;
   out->packed_weight_bytes = (exact ? g.packed32_floats * 4 : g.packed16_halfs * 2) + g.packed_bias_floats * 4;
+  return PCLSEG_OK;
+}
+
+int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) {
+  if (!buf || !cap) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "buf is NULL");
+  Graph g;
+  int rc = build_graph(desc, &g);
+  if (rc) return fail(nullptr, rc, g.error);
+  std::string out;
+  for (const Op& op : g.ops) {
+    std::string nm = op.name();
+    if (op.kind == OP_CONV && op.nsub == 2 && !op.sub[0].deconv) nm = nm.substr(0, nm.find('/')) + "/expand";
+    if (op.kind == OP_CAM) nm = nm.substr(0, nm.find('/'));
+    if (op.pool_fused) nm = "pool+" + nm;
+    if (op.up_fused) nm = "up+" + nm;
+    if (op.fsq_fused) nm += "+" + op.fsq.name;
+    if (op.head_fused) nm += "+" + op.hd.name + "+head";
+    if (op.kind == OP_HEAD) nm += "+head";
+    // multiply-accumulates of the launch per scan (every fused piece included)
+    const TensorInfo& ti = g.tensors[op.in];
+    int64_t macs = 0;
+    if (op.kind == OP_CAM) {
+      macs = (int64_t)ti.H * ti.W * 2 * op.cin_t * (op.cin_t / 16);
+      if (op.fsq_fused) macs += (int64_t)ti.H * ti.W * op.cin_t * op.fsq.cout;
+    } else if (op.kind != OP_POOL) {
+      int wo, pl;
+      same_pad(ti.W, op.pkw, op.sw, &wo, &pl);
+      int64_t hw = (int64_t)ti.H * wo;                       // output pixels of the main convolution
+      if (op.pool_fused) { same_pad(ti.W, 3, 2, &wo, &pl); hw = (int64_t)ti.H * wo; }
+      if (op.up_fused) {                                      // `in` is at half width
+        macs += (int64_t)ti.H * ti.W * 2 * 2 * op.cin_t * op.up[0].cout;
+        hw = (int64_t)ti.H * ti.W * 2;
+      }
+      if (op.ow_mul == 2) hw = (int64_t)ti.H * ti.W;          // transposed conv: each parity sub-conv covers Win columns
+      for (int i = 0; i < op.nsub; ++i) macs += hw * op.sub[i].nkh * op.sub[i].nkw * op.cin_k * op.sub[i].cout;
+      if (op.sk_in >= 0) macs += hw * 6 * op.sk.cout;
+      if (op.fsq_fused) macs += hw * (op.sub[0].cout + op.sub[1].cout) * op.fsq.cout;
+      if (op.head_fused) macs += hw * 9 * 64 * op.hd.cout;
+    }
+    out += nm + "\t" + std::to_string(macs) + "\n";
+  }
+  if (out.size() + 1 > cap) return fail(nullptr, PCLSEG_ERR_BAD_ARG, fmt("buffer of %zu bytes, the op list needs %zu", cap, out.size() + 1));
+  memcpy(buf, out.c_str(), out.size() + 1);
   return PCLSEG_OK;
 }
 

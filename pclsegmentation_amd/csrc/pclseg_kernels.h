@@ -135,6 +135,10 @@ __device__ __forceinline__ f32x4 fma4(const f32x4 a, const float s, const f32x4 
   return r;
 }
 
+// Workgroup barrier that leaves this wave's global loads in flight: __syncthreads() drains vmcnt too, which
+// would turn every prefetch issued before it into a stall at it.  LDS traffic is ordered by lgkmcnt.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
   return fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -279,8 +283,19 @@ __device__ __forceinline__ void head_finish(const f32x4 (&lv)[NTW], const bool v
 // up-convolved patch from memory, the waves compute it — 16 patch pixels of one output parity per MFMA
 // tile, K = 2 taps x C straight from the half-width squeeze tensor — and write it to LDS in the staged
 // split-f16 layout.  Four launches and the four up-convolved tensors disappear.
-template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0, int UP = 0>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const ConvArgs a) {
+// LW = loader waves (8-wave single-conv blocks of Darknet's wide layers, one block per CU): LW extra waves do
+// nothing but stage the NEXT channel chunk's patch into a second LDS buffer while the NW compute waves run the
+// current chunk's K loop — one barrier per chunk, no staging in the compute waves, and the loaders' memory
+// round trips are counted in their own vmcnt.  Measured need (s_memtime stamps, round 3): in the 512 -> 1024
+// 3x3 layers a chunk's K loop runs at 99 % of the matrix rate (28 k cycles) but the staging between two K
+// loops takes 14.5 k cycles with idle matrix cores — every block of the chip stages at the same moment, one
+// block per CU (147-226 registers), so nothing overlaps it.  Prefetching the next chunk into registers of the
+// compute waves does not help (+0.4 %): vmcnt retires in order, so the K loop's first weight-fragment wait
+// also waits for the prefetch.  Capping the registers at 128 for two blocks per CU spills (+3.7 % only, and
+// the two blocks stage in lockstep anyway).
+// OCC128: 8-wave single-conv variant whose register allocation is capped at 128 (two blocks per CU).
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0, int UP = 0, int LW = 0, bool OCC128 = false>
+__global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 : 4)) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int kThreads = NW * 64;
   const int tid = threadIdx.x;
@@ -349,7 +364,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
     for (int i = tid; i < (9 * a.out_C) >> 2; i += kThreads)
       dst[i] = *reinterpret_cast<const f32x4*>(a.skw + i * 4);
   }
-  auto epilogue = [&](const ConvSub& E, f32x4 (&ac)[MTW][NTW]) {
+  // (mlo, mhi: the segments to finish — the register-capped 8-segment variant does it in two halves)
+  auto epilogue = [&](const ConvSub& E, f32x4 (&ac)[MTW][NTW], const int mlo = 0, const int mhi = MTW) {
     // opaque copies of the lane coordinates: everything the epilogue derives from them is computed
     // HERE, not hoisted above the K loop where it would cost registers for its whole duration
     int p = lane & 15, g = lane >> 4;
@@ -377,6 +393,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       bool validm[MTW];
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
+        if (m < mlo || m >= mhi) continue;
         const int oh = h0 + seg_r[m];
         const int j = w0 + seg_q[m] * 16 + p;
         validm[m] = (oh < a.H) && (j < a.Wconv);
@@ -387,6 +404,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
           for (int nn = 0; nn < NTW; ++nn) {
+            if (m < mlo || m >= mhi) continue;
             const int co = (ct0 + nn) * 16 + g * 4;
             const bool ok = validm[m] && co < E.Cout;
             r1[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res1 + pixm[m] * a.res1_C + E.co_off + co : a.res1);
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
           for (int nn = 0; nn < NTW; ++nn) {
+            if (m < mlo || m >= mhi) continue;
             const int co = (ct0 + nn) * 16 + g * 4;
             const bool ok = validm[m] && co < E.Cout;
             r2[m][nn] = *reinterpret_cast<const f32x4*>(ok ? a.res2 + pixm[m] * a.res2_C + E.co_off + co : a.res2);
@@ -405,6 +424,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       if constexpr (kSk) if (a.skx) {
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
+          if (m < mlo || m >= mhi) continue;
           const float* xp = validm[m] ? a.skx + pixm[m] * 8 : a.skx;
           sx0[m] = *reinterpret_cast<const f32x4*>(xp);
           sx1[m] = *reinterpret_cast<const f32x4*>(xp + 4);
@@ -424,6 +444,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
         }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
+          if (m < mlo || m >= mhi) continue;
           if (validm[m] && co < E.Cout) {
             f32x4 v = act4(pre(ac[m][nn], nn), E.act);
             if constexpr (kR1) if (a.res1) v = a.res1_mul ? v * r1[m][nn] : v + r1[m][nn];
@@ -559,15 +580,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
     for (int m = 0; m < MTW; ++m)
       pixoff[m] = (seg_r[m] * a.PW + (seg_q[m] * 16 + p) * a.sw) * CSh;
 
-    const int sq = tid & (qs - 1);        // this thread's unit (fixed: kThreads % qs == 0)
-    const int spix0 = tid >> lq;
-    const int spstep = kThreads >> lq;
+    // staging threads: all of the block, or (LW > 0) the LW loader waves behind the NW compute waves
+    constexpr int kStageThreads = LW ? LW * 64 : kThreads;
+    const int stid = LW ? tid - kThreads : tid;
+    const int sq = stid & (qs - 1);        // this thread's unit (fixed: kStageThreads % qs == 0)
+    const int spix0 = stid >> lq;
+    const int spstep = kStageThreads >> lq;
     const int hbase = h0 - a.pt, wbase = w0 * a.sw - a.pl;
 
     // stage the channel chunk [c8_0, c8_0 + ck8) (8-channel groups) of the patch into LDS
-    auto stage = [&](const int c8_0, const int ck8) {
+    auto stage = [&](const int c8_0, const int ck8, _Float16* const sm) {   // (sm: the LDS buffer to fill)
+      // loads a thread keeps in flight: loader waves have nothing else to do and a chunk's whole share
+      // (<= 12 units of a 10 x 18 patch x 64 channels over 256 threads) must be ONE round trip, not three
+      constexpr int kB = LW ? 12 : kStageBatch;
       if (a.in_s16) {
-        constexpr int kB = kStageBatch;
         const int hq = qs >> 1;
         const int pl_sel = sq >= hq ? 1 : 0;
         const int c8u = sq & (hq - 1);
@@ -598,10 +624,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       } else {
         const int c = c8_0 * 8 + sq * 4;
         const bool cok = (c < a.Cin) && (sq < ck8 * 2);
-        for (int pb = spix0; pb < npix; pb += kStageBatch * spstep) {
-          f32x4 v[kStageBatch];
+        for (int pb = spix0; pb < npix; pb += kB * spstep) {
+          f32x4 v[kB];
 #pragma unroll
-          for (int k = 0; k < kStageBatch; ++k) {
+          for (int k = 0; k < kB; ++k) {
             const int pix = pb + k * spstep;
             const int pr = (int)(((unsigned)pix * (unsigned)a.inv_pw) >> 20);
             const int pc = pix - pr * a.PW;
@@ -613,7 +639,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
             v[k] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-          for (int k = 0; k < kStageBatch; ++k) {
+          for (int k = 0; k < kB; ++k) {
             const int pix = pb + k * spstep;
             f16x4 hi, lo;
             split4(v[k], hi, lo);
@@ -715,7 +741,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       }
     };
 
-    auto kloop = [&](const ConvSub& K, const int chunk, const int ck8) {
+    auto kloop = [&](const ConvSub& K, const int chunk, const int ck8, const _Float16* const sm) {   // (sm: the LDS buffer to read)
         const int ntaps = K.nkh * K.nkw;
         const int steps_full = (ntaps * ck8_full + 3) >> 2;
         const int nk = ntaps * ck8;
@@ -742,20 +768,27 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           const int c8 = kidx - __mul24(tap, ck8);
           const int ti = __mul24(tap, inv_kw) >> 16;
           const int koff = origin + __mul24(__mul24(ti, a.PW) + (tap - __mul24(ti, K.nkw)), CSh) + c8 * 8;
-          f16x8 xh[MTW], xl[MTW];
+          // (8-segment register tiles read their activation fragments in two halves: 64 registers of
+          // fragments at once is what pushed those kernels past 128 registers, i.e. to one block per CU)
+          constexpr int MB = (MTW == 8 && OCC128) ? 4 : MTW;
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) {
-            xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m] + koff);
-            xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m] + koff);
-          }
+          for (int m0 = 0; m0 < MTW; m0 += MB) {
+            f16x8 xh[MB], xl[MB];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int nn = 0; nn < NTW; ++nn) {
-              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nn], xh[m], acc[m][nn], 0, 0, 0);
-              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xl[m], acc[m][nn], 0, 0, 0);
-              acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xh[m], acc[m][nn], 0, 0, 0);
+            for (int m = 0; m < MB; ++m) {
+              xh[m] = *reinterpret_cast<const f16x8*>(sm + pixoff[m0 + m] + koff);
+              xl[m] = *reinterpret_cast<const f16x8*>(sm + plane + pixoff[m0 + m] + koff);
             }
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+              for (int nn = 0; nn < NTW; ++nn) {
+                acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nn], xh[m], acc[m0 + m][nn], 0, 0, 0);
+                acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xl[m], acc[m0 + m][nn], 0, 0, 0);
+                acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nn], xh[m], acc[m0 + m][nn], 0, 0, 0);
+              }
+            if (MB < MTW && m0 == 0) asm volatile("" ::: "memory");
+          }
         };
         // Weight fragments stream from L2 through a 2-deep register ring: the loads of step s+2
         // are issued as soon as step s has consumed its slot.
@@ -776,7 +809,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
       // same staged patch) through the same accumulators — ONE instance of the K loop and of the
       // epilogue, run twice (code size: a kernel that does not fit the instruction cache pays for it
       // on every launch)
-      if constexpr (UP > 0) stage_up(); else stage(0, cin8);
+      if constexpr (UP > 0) stage_up(); else stage(0, cin8, sm);
       __syncthreads();
       stamp(1);
       // Every block of a launch starts at the same time; if all of them ran 3x3 -> store -> 1x1 ->
@@ -801,7 +834,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
 #pragma unroll
             for (int nn = 0; nn < NTW; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        kloop(K, 0, cin8);
+        kloop(K, 0, cin8, sm);
         stamp(2 + 2 * half);
         if constexpr (FSQ == 0) {
           epilogue(K, acc);
@@ -912,21 +945,62 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 4) void conv_kernel(const Co
           }
         }
       }
+    } else if constexpr (LW > 0) {
+      // two LDS buffers; loaders fill buffer (c + 1) & 1 while the compute waves read buffer c & 1.  Barrier
+      // #c (c = 0 .. nchunks - 1) is passed by the loaders after staging chunk c and by the compute waves
+      // before its K loop — i.e. after the K loop of chunk c - 1, which frees buffer (c + 1) & 1 for chunk c + 1.
+      const int nchunks = (cin8 + ck8_full - 1) / ck8_full;
+      const int buf_halfs = (2 * plane + 7) & ~7;
+      if (wave >= NW) {
+        // A loader shares its SIMD with two compute waves that keep the matrix pipe and half of the vector issue
+        // slots busy, and as the YOUNGEST wave it loses every arbitration: without priority a chunk's staging
+        // took 38 k cycles beside a K loop (11 k alone) and the compute waves waited for it.
+        __builtin_amdgcn_s_setprio(3);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+          const int c8_0 = chunk * ck8_full;
+          const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
+          stage(c8_0, ck8, sm + (chunk & 1) * buf_halfs);
+#ifdef PCLSEG_WITH_STAMPS
+          if (a.stamps && tid == kThreads && (chunk == 1 || chunk == 2)) a.stamps[(size_t)blockIdx.x * 8 + 4 + chunk] = __builtin_amdgcn_s_memtime();
+#endif
+          __syncthreads();
+        }
+        if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
+        return;
+      }
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c8_0 = chunk * ck8_full;
+        const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
+        lds_barrier();
+        if (chunk == 0) stamp(1);
+        if (chunk == 1) stamp(3);
+        kloop(S, chunk, ck8, sm + (chunk & 1) * buf_halfs);
+        if (chunk == 0) stamp(2);
+        if (chunk == 1) stamp(4);
+      }
     } else {
       int chunk = 0;
       for (int c8_0 = 0; c8_0 < cin8; c8_0 += ck8_full, ++chunk) {
         const int ck8 = (cin8 - c8_0) < ck8_full ? (cin8 - c8_0) : ck8_full;
         if (chunk) __syncthreads();
-        stage(c8_0, ck8);
+        stage(c8_0, ck8, sm);
         __syncthreads();
         stamp(chunk < 2 ? 1 + 2 * chunk : 5);
-        kloop(S, chunk, ck8);
+        kloop(S, chunk, ck8, sm);
         stamp(chunk < 2 ? 2 + 2 * chunk : 5);
       }
       if (chunk < 2) { stamp(3); stamp(4); }
-      stamp(5);
-      epilogue(S, acc);
-      stamp(6);
+    }
+    if constexpr (!PAIR) {
+      if constexpr (LW == 0) stamp(5);
+      if constexpr (OCC128 && MTW == 8) {
+        epilogue(S, acc, 0, 4);
+        asm volatile("" ::: "memory");
+        epilogue(S, acc, 4, 8);
+      } else {
+        epilogue(S, acc);
+      }
+      if constexpr (LW == 0) stamp(6);
     }
     stamp(7);
     if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
@@ -988,10 +1062,6 @@ constexpr int kFhLdsU = kFhUH * kFhUW * kFhCSU * 2;
 constexpr int kFhLds = kFhLdsF + kFhLdsU + 9 * 64 * 4;
 static_assert(kFhUH * kFhSW * kFhCSU * 2 <= kFhLdsF, "the source patch aliases F");
 static_assert(kFhFSeg == 12, "3 F segments per wave");
-
-// Workgroup barrier that leaves this wave's global loads in flight: __syncthreads() drains vmcnt too, which
-// would turn every prefetch issued before it into a stall at it.  LDS traffic is ordered by lgkmcnt.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // What was measured on the way (s_memtime stamps per phase, one lane, 4 scans):
 //   v1  weights streamed per wave through a 2-deep ring, operands fetched where used, __syncthreads():

@@ -29,7 +29,7 @@ ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
 
 # every symbol include/pclseg.h declares (checked by tests/test_host.py::test_library_exports_every_declared_symbol)
 EXPORTS = [
-  "pclseg_version", "pclseg_last_error", "pclseg_plan", "pclseg_create", "pclseg_destroy",
+  "pclseg_version", "pclseg_last_error", "pclseg_plan", "pclseg_plan_ops", "pclseg_create", "pclseg_destroy",
   "pclseg_num_weights", "pclseg_weight_info", "pclseg_set_weight", "pclseg_finalize",
   "pclseg_packed_size", "pclseg_export_packed", "pclseg_import_packed",
   "pclseg_set_stream", "pclseg_sync", "pclseg_host_alloc", "pclseg_host_free", "pclseg_forward", "pclseg_forward_raw",
@@ -85,6 +85,7 @@ def load_library():
   lib.pclseg_last_error.restype = ctypes.c_char_p
   lib.pclseg_last_error.argtypes = [vp]
   lib.pclseg_plan.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(PlanInfo)]
+  lib.pclseg_plan_ops.argtypes = [ctypes.POINTER(Desc), ctypes.c_char_p, ctypes.c_size_t]
   lib.pclseg_create.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(vp)]
   lib.pclseg_destroy.argtypes = [vp]
   lib.pclseg_num_weights.argtypes = [vp]
@@ -181,6 +182,20 @@ def plan(desc):
   info = PlanInfo()
   check(lib.pclseg_plan(ctypes.byref(desc), ctypes.byref(info)))
   return {k: getattr(info, k) for k, _ in PlanInfo._fields_}
+
+
+def plan_ops(desc):
+  """CPU-only: names of the kernel launches of one micro-batch, in launch order."""
+  buf = ctypes.create_string_buffer(1 << 16)
+  check(load_library().pclseg_plan_ops(ctypes.byref(desc), buf, len(buf)))
+  return [line.split("\t")[0] for line in buf.value.decode().splitlines()]
+
+
+def plan_op_macs(desc):
+  """CPU-only: [(launch name, multiply-accumulates per scan)] in launch order."""
+  buf = ctypes.create_string_buffer(1 << 16)
+  check(load_library().pclseg_plan_ops(ctypes.byref(desc), buf, len(buf)))
+  return [(l.split("\t")[0], int(l.split("\t")[1])) for l in buf.value.decode().splitlines()]
 
 
 def _host_f32(a):

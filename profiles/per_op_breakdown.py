@@ -59,6 +59,10 @@ if len(sys.argv) > 2:
 else:   # smallest period of the kernel-name sequence
   per = next((p for p in range(8, 80) if len(names) >= 3 * p and names[:2 * p] == names[p:3 * p]), 37)
 ops = {37: sequence(0), 32: sequence(1), 29: sequence(2), 26: sequence(2, True), 25: sequence(2, True, True), 21: sequence(2, True, True, False)}.get(per, [])
+if per == 20:   # round 3: fire13's expand pair, conv14 and the head are one launch
+  ops = sequence(2, True, True, False)[:-2] + ["fire13+conv14+head"]
+if not ops:     # Darknet (or an unknown plan): label by position + kernel family
+  ops = []
 agg = collections.defaultdict(list)
 for i, r in enumerate(rows):
   agg[i % per].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
