@@ -715,7 +715,7 @@ hipError_t launch_fire_head(const Op& op, FireHeadArgs f, int N, int H, int W, c
   f.up_bias = bias + op.up[0].b_off;
   f.e1_w16 = w16 + op.sub[0].w16_off; f.e1_bias = bias + op.sub[0].b_off;
   f.e3_w16 = w16 + op.sub[1].w16_off; f.e3_bias = bias + op.sub[1].b_off;
-  f.skw = bias + op.sk.b_off;
+  f.sk_w16 = w16 + op.skm.w16_off; f.sk_bias = bias + op.skm.b_off;
   f.hd_w16 = w16 + op.hd.w16_off; f.hd_bias = bias + op.hd.b_off;
   const dim3 grid((unsigned)(N * f.tilesH * f.tilesW));
 #ifdef PCLSEG_WITH_STAMPS
@@ -1339,7 +1339,7 @@ uint64_t plan_hash(const Graph& g) {
   for (const Op& op : g.ops) {
     mix(op.kind); mix(op.ntw); mix(op.wn); mix(op.mtw); mix(op.nw); mix(op.ck16); mix(op.ck32);
     mix(op.pair); mix(op.fsq_fused); mix(op.up_fused); mix(op.pool_fused); mix(op.head_fused);
-    if (op.head_fused) { mix(op.hd.w16_off); mix(op.hd.b_off); }
+    if (op.head_fused) { mix(op.hd.w16_off); mix(op.hd.b_off); mix(op.skm.w16_off); mix(op.skm.b_off); }
     for (int i = 0; i < op.nsub; ++i) { mix(op.sub[i].w16_off); mix(op.sub[i].w32_off); mix(op.sub[i].b_off); mix(op.sub[i].nctp); }
     if (op.fsq_fused) { mix(op.fsq.w16_off); mix(op.fsq.b_off); }
     if (op.up_fused) for (int i = 0; i < 2; ++i) { mix(op.up[i].w16_off); mix(op.up[i].b_off); }
@@ -1645,6 +1645,22 @@ int pclseg_finalize(pclseg_handle* h) {
       fold_bn(su, f, &scale, &shift);
       pack_bias(su, shift, bias.data() + su.b_off);
       pack_w16(as_head, su, f, scale, w16.data() + su.w16_off, bias.data() + su.b_off + su.nctp * 16, &stat);
+      // the skip branch (conv1_skip + bn1_skip, 6 -> 64) as ONE K-step of split-f16 fragments: its 8 (padded)
+      // input channels are K-group 0, the other three lane groups carry zeros
+      const SubOp& sm = op.skm;
+      FoldIn fs;
+      fs.kernel = W(sm.name + "/kernel"); fs.bias = W(sm.name + "/bias");
+      fs.gamma = W(sm.bn + "/gamma"); fs.beta = W(sm.bn + "/beta");
+      fs.mean = W(sm.bn + "/moving_mean"); fs.var = W(sm.bn + "/moving_variance");
+      if (!fs.kernel || !fs.bias || !fs.gamma || !fs.beta || !fs.mean || !fs.var)
+        return fail(h, PCLSEG_ERR_MISSING_WEIGHT, fmt("internal: parameters of '%s' not found", sm.name.c_str()));
+      Op as_skip;
+      as_skip.cin_t = 8;
+      as_skip.cin_k = (int)h->g.weights[h->g.weight_index[sm.name + "/kernel"]].shape[2];
+      as_skip.ck16 = 16;
+      fold_bn(sm, fs, &scale, &shift);
+      pack_bias(sm, shift, bias.data() + sm.b_off);
+      pack_w16(as_skip, sm, fs, scale, w16.data() + sm.w16_off, bias.data() + sm.b_off + sm.nctp * 16, &stat);
     }
     if (op.up_fused) {
       if (!want16) return fail(h, PCLSEG_ERR_STATE, "internal: fused up-convolution in an exact-f32 plan");

@@ -111,6 +111,7 @@ struct Op {
   // output tensor is never materialised and the op writes predictions / probabilities / logits
   bool head_fused = false;
   SubOp hd;
+  SubOp skm;   // head_fused: the skip branch as split-f16 fragments (K = 8 input channels in lane group 0), 4 cout tiles
   std::string name() const { return sub[0].name; }
 };
 
@@ -926,6 +927,12 @@ inline int build_graph(const pclseg_desc* d, Graph* g) {
       g->packed16_halfs += (int64_t)18 * op.hd.nctp * 1024;
       op.hd.b_off = g->packed_bias_floats;
       g->packed_bias_floats += sub_bias_floats(op.hd);
+      op.skm = op.sk;                     // one K-step x 4 cout tiles
+      op.skm.nctp = (op.sk.cout + 15) / 16;
+      op.skm.w16_off = g->packed16_halfs;
+      g->packed16_halfs += (int64_t)op.skm.nctp * 1024;
+      op.skm.b_off = g->packed_bias_floats;
+      g->packed_bias_floats += sub_bias_floats(op.skm);
     }
     if (op.up_fused) {   // the transposed conv's two parities, packed like any 2-tap sub-conv of this op
       for (int i = 0; i < 2; ++i) {

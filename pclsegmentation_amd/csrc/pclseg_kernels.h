@@ -1018,10 +1018,10 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
 //      16 pixels (flattened), split-f16 [hi 64|lo 64|pad]; pixels outside the image are ZERO (conv14's
 //      padding), not fire13 evaluated on padding
 // 72 KB per block: two blocks per CU, so one block's staging / epilogues overlap the other's K loops.
-//   phase 0  half-width squeeze patch (12 x 12 source pixels) -> LDS (aliases F), skip weights -> LDS
+//   phase 0  half-width squeeze patch (12 x 12 source pixels) -> LDS (aliases F)
 //   phase 1  up-convolution: wave <-> (output parity, half of the 16-pixel units), K = 2 taps x 16
 //   phase 2  expand pair on the 12 F segments (3 per wave, weight fragments fetched once per wave):
-//            3x3 half 5 K-steps + 1x1 half 1 K-step, bias/ReLU, skip branch from the 8-channel network
+//            3x3 half 5 K-steps + 1x1 half 1 K-step, bias/ReLU, skip branch (one more K-step) from the 8-channel network
 //            input (32 B per pixel from L2), zero outside the image, split -> F
 //   phase 3  conv14 on the 8 tile rows (2 per wave): 18 K-steps over (tap, 8-channel group) pairs of F,
 //            packed head fragments streamed through a 2-deep ring, then head_finish
@@ -1041,7 +1041,8 @@ struct FireHeadArgs {
   const _Float16* e3_w16;
   const float* e1_bias;        // [bias 32 | inv 32]
   const float* e3_bias;
-  const float* skw;            // [8][64] folded conv1_skip weights + [64] bias
+  const _Float16* sk_w16;      // skip branch conv1_skip + bn1_skip: one K-step (8 input channels = K-group 0) x 4 cout tiles
+  const float* sk_bias;        // [bias 64 | inv 64]
   const _Float16* hd_w16;      // conv14: 18 K-steps x NCT tiles (packed with a 64-channel chunk)
   const float* hd_bias;        // [bias NCT*16 | inv NCT*16]
   unsigned* range_flag;
@@ -1059,7 +1060,7 @@ constexpr int kFhCSF = 2 * 64 + kPadF16;              // halfs per F pixel
 constexpr int kFhFSeg = (kFhFH * kFhFW + 15) / 16;    // 12 segments
 constexpr int kFhLdsF = kFhFSeg * 16 * kFhCSF * 2;    // bytes
 constexpr int kFhLdsU = kFhUH * kFhUW * kFhCSU * 2;
-constexpr int kFhLds = kFhLdsF + kFhLdsU + 9 * 64 * 4;
+constexpr int kFhLds = kFhLdsF + kFhLdsU;
 static_assert(kFhUH * kFhSW * kFhCSU * 2 <= kFhLdsF, "the source patch aliases F");
 static_assert(kFhFSeg == 12, "3 F segments per wave");
 
@@ -1080,7 +1081,6 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   _Float16* F = reinterpret_cast<_Float16*>(smem_raw);
   _Float16* S = F;                                                       // source patch (dead before F is written)
   _Float16* U = reinterpret_cast<_Float16*>(smem_raw + kFhLdsF);
-  float* skw_lds = reinterpret_cast<float*>(smem_raw + kFhLdsF + kFhLdsU);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1127,9 +1127,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   const f16x8 uwl = *reinterpret_cast<const f16x8*>(a.up_w16[parity] + 512 + lane8);
   const f32x4 ub = *reinterpret_cast<const f32x4*>(a.up_bias + parity * 32 + g * 4);
   const float ui = sload(a.up_bias + parity * 32 + 16);
-  // (3) skip-branch weights -> LDS (through a register); the raw input's addresses of this wave's 3 F segments
-  f32x4 skq = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (tid < 9 * 64 / 4) skq = *reinterpret_cast<const f32x4*>(a.skw + tid * 4);
+  // (3) the skip branch's raw-input addresses of this wave's 3 F segments
   int uoff[3];
   bool fvalid[3], fimg[3];
   const float* sxp[3];
@@ -1181,7 +1179,6 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     const int i = tid + k * 256;
     if (i < kSrcUnits) *reinterpret_cast<f16x8*>(S + (i >> 2) * kFhCSU + (i & 3) * 8) = sv[k];
   }
-  if (tid < 9 * 64 / 4) *reinterpret_cast<f32x4*>(skw_lds + tid * 4) = skq;
   lds_barrier();
   stamp(1);
 
@@ -1301,34 +1298,46 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     stamp(4);
     asm volatile("" ::: "memory");
     load_hw(0); load_hw(1); load_hw(2);   // (the last two steps' follow the epilogue: register budget)
-    // bias + ReLU, + skip branch (nets/SqueezeSegV2.py:293,319), zero outside the image, split -> F
+    // bias + ReLU, + skip branch (nets/SqueezeSegV2.py:293,319), zero outside the image, split -> F.
+    // The skip branch (1x1 conv of the 8-channel input) runs on the matrix cores too: K = 8 is one quarter
+    // of a 32-deep step (lane group 0), three MFMAs per (segment, cout tile) instead of 32 FMAs + 9 LDS reads —
+    // this kernel is bound by vector-instruction issue, the matrix pipe has room.
+    f16x8 sxh[3], sxl[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = g == 0 ? sx0[m][e] : 0.0f, x1 = g == 0 ? sx1[m][e] : 0.0f;
+        const _Float16 h0v = (_Float16)x0, h1v = (_Float16)x1;
+        sxh[m][e] = h0v; sxh[m][4 + e] = h1v;
+        sxl[m][e] = (_Float16)(x0 - (float)h0v); sxl[m][4 + e] = (_Float16)(x1 - (float)h1v);
+      }
+      vmax = absmax4(absmax4(vmax, sx0[m]), sx1[m]);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float* bb = t < 2 ? a.e1_bias : a.e3_bias;
       const int tt = t & 1, co = t * 16 + g * 4;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + tt * 16 + g * 4);
       const float iv = sload(bb + 32 + tt * 16);
+      const f16x8 kwh = *reinterpret_cast<const f16x8*>(a.sk_w16 + t * 1024 + lane8);
+      const f16x8 kwl = *reinterpret_cast<const f16x8*>(a.sk_w16 + t * 1024 + 512 + lane8);
+      const f32x4 kb = *reinterpret_cast<const f32x4*>(a.sk_bias + t * 16 + g * 4);
+      const float ki = sload(a.sk_bias + 64 + t * 16);
       f32x4 z[3];
 #pragma unroll
-      for (int m = 0; m < 3; ++m) z[m] = *reinterpret_cast<const f32x4*>(skw_lds + 8 * 64 + co);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {   // one weight quad at a time (all nine at once cost 36 registers)
-        const f32x4 wa = *reinterpret_cast<const f32x4*>(skw_lds + c * 64 + co);
-        const f32x4 wb = *reinterpret_cast<const f32x4*>(skw_lds + (4 + c) * 64 + co);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) z[m][e] = fmaf(sx0[m][c], wa[e], z[m][e]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) z[m][e] = fmaf(sx1[m][c], wb[e], z[m][e]);
-        }
+      for (int m = 0; m < 3; ++m) {
+        z[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwl, sxh[m], z[m], 0, 0, 0);
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwh, sxl[m], z[m], 0, 0, 0);
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwh, sxh[m], z[m], 0, 0, 0);
       }
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         f32x4 v = fma4(acc[m][t], iv, bv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-        v += z[m];
+        v += fma4(z[m], ki, kb);
         if (!fimg[m]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         vmax = absmax4(vmax, v);
         f16x4 hi, lo;
