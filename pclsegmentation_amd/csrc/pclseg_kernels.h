@@ -1072,7 +1072,12 @@ static_assert(kFhFSeg == 12, "3 F segments per wave");
 //   v3  persistent blocks (2 per CU) with the next tile's patch requested a phase ahead: 161 us, and 3-lane
 //       throughput 5700 instead of 6390 scans/s — resident blocks hold 144 KB of LDS per CU for the whole
 //       launch and shut the other lanes' kernels out; the prefetched operands spilled to scratch
-//   v4  8 waves per block at 128 registers (4 waves per SIMD): 206 us — register spills in the F epilogue
+//   v4  8 waves per block at 128 registers (4 waves per SIMD; phase 2 split by segment group x cout half, phase 3
+//       by K group x cout tile), built twice — with the VALU skip branch (206 us) and with the skip branch on
+//       the matrix cores and scheduling barriers around the staggered loads (228 us): the allocation never got
+//       below 128 registers without 200 bytes of scratch per lane, and every use of scratch in this kernel
+//       has cost a factor, not a percentage
+//   v5  v2 + the skip branch as one more K-step on the matrix cores (-400 vector instructions per wave): 119 us
 // The block is bound by instruction issue, not by any pipe: ~2000 vector + ~1100 scalar + ~250 LDS
 // instructions per wave and tile beside 351 MFMAs, at two waves per SIMD.
 template <int NCT>
