@@ -630,9 +630,14 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
       // 128 px x 256 couts: the register-capped variant (two blocks per CU).  Tuning build: PCLSEG_DN_VARIANT = 0 the
       // uncapped kernel (147-226 registers, one block per CU), 1 capped, 2 loader waves (conv_kernel LW; measured: no gain)
       static const int variant = tune_env("PCLSEG_DN_VARIANT", 1);
-#define PCLSEG_CAP(E_) hipLaunchKernelGGL((conv_kernel<8, 2, 8, false, true, E_, false, 8, 0, 0, 0, true>), grid, dim3(512), lds, s, a)
+#define PCLSEG_CAP(E_, G_) hipLaunchKernelGGL((conv_kernel<8, 2, 8, false, true, E_, false, 8, 0, 0, 0, true, G_>), grid, dim3(512), lds, s, a)
       if (variant == 1) {
-        switch (epi) { case 0: PCLSEG_CAP(0); break; case 1: PCLSEG_CAP(1); break; default: PCLSEG_CAP(2); break; }
+        // 3x3, stride 1, every chunk a full 64 channels: the fully unrolled K loop with immediate addressing (GEOM 1)
+        static const int geom_on = tune_env("PCLSEG_DN_GEOM", 1);
+        const bool g1 = geom_on && op.pkh == 3 && op.pkw == 3 && op.sw == 1 && op.nsub == 1 && op.ck16 == 64 && op.cin_t % 64 == 0 &&
+                        a.PW == 18 && a.PH == 10 && op.sub[0].nkh == 3 && op.sub[0].nkw == 3 && op.sub[0].th0 == 0 && op.sub[0].tw0 == 0;
+        if (g1) { switch (epi) { case 0: PCLSEG_CAP(0, 1); break; case 1: PCLSEG_CAP(1, 1); break; default: PCLSEG_CAP(2, 1); break; } }
+        else { switch (epi) { case 0: PCLSEG_CAP(0, 0); break; case 1: PCLSEG_CAP(1, 0); break; default: PCLSEG_CAP(2, 0); break; } }
         return hipGetLastError();
       }
 #undef PCLSEG_CAP

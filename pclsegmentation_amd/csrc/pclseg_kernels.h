@@ -294,7 +294,13 @@ __device__ __forceinline__ void head_finish(const f32x4 (&lv)[NTW], const bool v
 // also waits for the prefetch.  Capping the registers at 128 for two blocks per CU spills (+3.7 % only, and
 // the two blocks stage in lockstep anyway).
 // OCC128: 8-wave single-conv variant whose register allocation is capped at 128 (two blocks per CU).
-template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0, int UP = 0, int LW = 0, bool OCC128 = false>
+// GEOM = 1 (with OCC128, 8 x 16-pixel tiles): the geometry of Darknet's heavy layers — 3x3, stride 1, full
+// 64-channel chunks (patch 10 x 18 pixels, 72 halfs per pixel and plane) — is a compile-time constant, so
+// the K loop is fully unrolled and EVERY activation-fragment address is one per-lane base register plus an
+// immediate: the generic loop spends ~19 vector adds, ~15 register moves and ~15 waits per K-step on them
+// beside 48 MFMAs, and at two to four waves per SIMD that issue traffic is what held its K loop at 72 % of
+// the matrix rate (s_memtime stamps, round 3).
+template <int MTW, int NTW, int WN, bool HEAD, bool F16X3, int EPI, bool PAIR = false, int NW = 4, int FSQ = 0, int UP = 0, int LW = 0, bool OCC128 = false, int GEOM = 0>
 __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 : 4)) void conv_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int kThreads = NW * 64;
@@ -742,6 +748,55 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
     };
 
     auto kloop = [&](const ConvSub& K, const int chunk, const int ck8, const _Float16* const sm) {   // (sm: the LDS buffer to read)
+      if constexpr (GEOM == 1) {
+        static_assert(MTW == 8 && WN == 8 && NW == 8, "GEOM 1 is the 8 x 16-pixel tile of the 8-wave blocks");
+        constexpr int kPW = 18, kCS = 72, kPlane = 10 * 18 * 72, kSteps = 18;   // (host-checked against a.PW / CSh / plane)
+        const _Float16* wb = K.w16 + ((size_t)(chunk * kSteps) * K.nctp + ct0) * 1024;   // scalar
+        const unsigned wstep = (unsigned)K.nctp * 1024u;
+        const unsigned lane8 = (unsigned)lane * 8u;
+        const _Float16* xb = sm + p * kCS + g * 8;   // segment m = tile row m: + m * kPW * kCS; lane group g = channel group 4 (s & 1) + g
+        f16x8 wh[2][NTW], wl[2][NTW];
+        auto load_w = [&](const int s, const int slot) {
+          const _Float16* wp = wb + (size_t)s * wstep;
+#pragma unroll
+          for (int nn = 0; nn < NTW; ++nn) {
+            wh[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + lane8);
+            wl[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512 + lane8);
+          }
+        };
+        load_w(0, 0);
+        load_w(1, 1);
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+          const int tap = s >> 1, ti = tap / 3, tj = tap - 3 * ti;
+          const int off = (ti * kPW + tj) * kCS + (s & 1) * 32;
+          const int slot = s & 1;
+#pragma unroll
+          for (int m0 = 0; m0 < 8; m0 += 4) {
+            f16x8 xh[4], xl[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              xh[m] = *reinterpret_cast<const f16x8*>(xb + off + (m0 + m) * (kPW * kCS));
+              xl[m] = *reinterpret_cast<const f16x8*>(xb + off + (m0 + m) * (kPW * kCS) + kPlane);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int nn = 0; nn < NTW; ++nn) {
+                acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot][nn], xh[m], acc[m0 + m][nn], 0, 0, 0);
+                acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][nn], xl[m], acc[m0 + m][nn], 0, 0, 0);
+                acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][nn], xh[m], acc[m0 + m][nn], 0, 0, 0);
+              }
+            // (864 straight-line MFMAs invite the scheduler to hoist every read of the chunk to the top — 1.6 KB of
+            // scratch per lane; nothing may cross a half-step.  With four waves per SIMD a wave owns the matrix pipe a
+            // quarter of the time, so its own read latency needs no software pipelining.)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (s + 2 < kSteps) load_w(s + 2, slot);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
         const int ntaps = K.nkh * K.nkw;
         const int steps_full = (ntaps * ck8_full + 3) >> 2;
         const int nk = ntaps * ck8;
