@@ -381,6 +381,15 @@ inline bool pair_cfg_ok(const Op& op) {
 #define PCLSEG_FSQ_CFGS(X) X(4, 2, 8, 4, 0) X(2, 3, 4, 3, 0) X(2, 3, 4, 4, 0) X(4, 1, 8, 2, 0) \
                            X(4, 1, 8, 2, 1) X(4, 1, 4, 1, 1) X(4, 1, 2, 1, 1)
 hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
+  // fire8 / fire9 (64 -> 256 + 256 -> 64, 4 x 16-pixel tiles): the compile-time geometry of conv_kernel GEOM 1
+  static const int geom_on = tune_env("PCLSEG_FSQ_GEOM", 1);
+  if (geom_on && op.mtw == 4 && op.ntw == 2 && op.wn == 8 && a.fsq_q == 64 && epi == 0 && op.cin_t == 64 && a.in_s16 &&
+      a.PW == 18 && a.PH == 6 && op.ck16 == 64 && !op.up_fused) {
+    auto kfn = conv_kernel<4, 2, 8, false, true, 0, true, 8, 4, 0, 0, false, 1>;
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds)) return e;
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+  }
 #define PCLSEG_X(M_, N_, W_, Q_, E_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16 && epi == E_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_>; \

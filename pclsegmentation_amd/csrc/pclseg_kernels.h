@@ -749,30 +749,16 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
 
     auto kloop = [&](const ConvSub& K, const int chunk, const int ck8, const _Float16* const sm) {   // (sm: the LDS buffer to read)
       if constexpr (GEOM == 1) {
-        static_assert(MTW == 8 && WN == 8 && NW == 8, "GEOM 1 is the 8 x 16-pixel tile of the 8-wave blocks");
-        constexpr int kPW = 18, kCS = 72, kPlane = 10 * 18 * 72, kSteps = 18;   // (host-checked against a.PW / CSh / plane)
-        const _Float16* wb = K.w16 + ((size_t)(chunk * kSteps) * K.nctp + ct0) * 1024;   // scalar
+        static_assert((MTW == 8 || MTW == 4) && WN == 8 && NW == 8, "GEOM 1: MTW x 16-pixel tiles (one segment per tile row) of the 8-wave blocks");
+        constexpr int kPW = 18, kCS = 72, kPlane = (MTW + 2) * 18 * 72;   // (host-checked against a.PW / CSh / plane)
         const unsigned wstep = (unsigned)K.nctp * 1024u;
         const unsigned lane8 = (unsigned)lane * 8u;
         const _Float16* xb = sm + p * kCS + g * 8;   // segment m = tile row m: + m * kPW * kCS; lane group g = channel group 4 (s & 1) + g
         f16x8 wh[2][NTW], wl[2][NTW];
-        auto load_w = [&](const int s, const int slot) {
-          const _Float16* wp = wb + (size_t)s * wstep;
+        // one K-step: `off` = the tap's patch offset + the step's channel half, compile-time after unrolling
+        auto gstep = [&](const int off, const int slot) {
 #pragma unroll
-          for (int nn = 0; nn < NTW; ++nn) {
-            wh[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + lane8);
-            wl[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512 + lane8);
-          }
-        };
-        load_w(0, 0);
-        load_w(1, 1);
-#pragma unroll
-        for (int s = 0; s < kSteps; ++s) {
-          const int tap = s >> 1, ti = tap / 3, tj = tap - 3 * ti;
-          const int off = (ti * kPW + tj) * kCS + (s & 1) * 32;
-          const int slot = s & 1;
-#pragma unroll
-          for (int m0 = 0; m0 < 8; m0 += 4) {
+          for (int m0 = 0; m0 < MTW; m0 += 4) {
             f16x8 xh[4], xl[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -787,13 +773,45 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
                 acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][nn], xl[m], acc[m0 + m][nn], 0, 0, 0);
                 acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][nn], xh[m], acc[m0 + m][nn], 0, 0, 0);
               }
-            // (864 straight-line MFMAs invite the scheduler to hoist every read of the chunk to the top — 1.6 KB of
-            // scratch per lane; nothing may cross a half-step.  With four waves per SIMD a wave owns the matrix pipe a
-            // quarter of the time, so its own read latency needs no software pipelining.)
+            // (hundreds of straight-line MFMAs invite the scheduler to hoist every read of the chunk to the top —
+            // 1.6 KB of scratch per lane; nothing may cross a half-step.  With four waves per SIMD a wave owns the
+            // matrix pipe a quarter of the time, so its own read latency needs no software pipelining.)
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (s + 2 < kSteps) load_w(s + 2, slot);
-          __builtin_amdgcn_sched_barrier(0);
+        };
+        if (K.nkh == 3) {   // 3x3: 18 K-steps, tap s / 2
+          constexpr int kSteps = 18;
+          const _Float16* wb = K.w16 + ((size_t)(chunk * kSteps) * K.nctp + ct0) * 1024;   // scalar
+          auto load_w = [&](const int st, const int slot) {
+            const _Float16* wp = wb + (size_t)st * wstep;
+#pragma unroll
+            for (int nn = 0; nn < NTW; ++nn) {
+              wh[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + lane8);
+              wl[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512 + lane8);
+            }
+          };
+          load_w(0, 0);
+          load_w(1, 1);
+#pragma unroll
+          for (int st = 0; st < kSteps; ++st) {
+            const int tap = st >> 1, ti = tap / 3, tj = tap - 3 * ti;
+            gstep((ti * kPW + tj) * kCS + (st & 1) * 32, st & 1);
+            if (st + 2 < kSteps) load_w(st + 2, st & 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {            // 1x1 half of a merged pair: the centre tap, 2 K-steps
+          const _Float16* wb = K.w16 + ((size_t)(chunk * 2) * K.nctp + ct0) * 1024;
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            const _Float16* wp = wb + (size_t)st * wstep;
+#pragma unroll
+            for (int nn = 0; nn < NTW; ++nn) {
+              wh[st][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + lane8);
+              wl[st][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512 + lane8);
+            }
+          }
+#pragma unroll
+          for (int st = 0; st < 2; ++st) gstep((1 * kPW + 1) * kCS + st * 32, st);
         }
         return;
       }
