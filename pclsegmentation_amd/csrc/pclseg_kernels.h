@@ -779,7 +779,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
             __builtin_amdgcn_sched_barrier(0);
           }
         };
-        if (K.nkh == 3) {   // 3x3: 18 K-steps, tap s / 2
+        if (!PAIR || K.nkh == 3) {   // 3x3: 18 K-steps, tap s / 2 (single convs are always 3x3 here: host-checked)
           constexpr int kSteps = 18;
           const _Float16* wb = K.w16 + ((size_t)(chunk * kSteps) * K.nctp + ct0) * 1024;   // scalar
           auto load_w = [&](const int st, const int slot) {
