@@ -234,3 +234,24 @@ def test_split_f16_weights_keep_22_bits(kh, cin, cout, sigma):
   old = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - kd)[nz] / np.abs(kd)[nz]
   if sigma < 0.02:
     assert np.percentile(old, 99) > 1e-5      # (documents the defect the scale removes)
+
+
+@pytest.mark.parametrize("arch,cfg,h,w", [("squeezesegv2", C.SqueezeSegV2KittiConfig, 64, 2048),
+                                         ("darknet21", C.Darknet21, 32, 1024), ("darknet53", C.Darknet53Kitti, 64, 2048)])
+def test_plan_ops_lists_every_launch_with_its_macs(arch, cfg, h, w):
+  """pclseg_plan_ops (profile labels): one line per kernel launch of a micro-batch, and the per-launch
+  multiply-accumulates add up to the plan's ALG figure exactly — fused pieces (next squeeze, up-convolution,
+  skip branch, head) are counted in the launch that computes them."""
+  mc = cfg()
+  d = E.make_desc(arch, h, w, mc.NUM_CLASS, mc.CLASSES.index("None"), mc.INPUT_MEAN, mc.INPUT_STD,
+                  output_stride=mc.get("OUTPUT_STRIDE", 16))
+  info = E.plan(d)
+  ops = E.plan_op_macs(d)
+  assert len(ops) == info["num_ops"] and E.plan_ops(d) == [n for n, _ in ops]
+  assert sum(m for _, m in ops) == info["alg_macs_per_scan"]
+  names = [n for n, _ in ops]
+  if arch == "squeezesegv2":
+    assert names[0] == "conv1" and names[-1] == "up+fire13/expand+conv14+head" and "cam2+fire3/squeeze" in names
+    assert len(names) == 19                      # + the pre-processing launch = 20 per micro-batch
+  else:
+    assert names[-1] == "head+head" and "enc5/residual_0/conv2" in names
