@@ -95,7 +95,13 @@ def broadcast_engine(model, height, width, flags=0, src=0, device=None):
   blob = torch.empty(eng.packed_size(), dtype=torch.uint8, device=device)
   if is_src:
     eng.export_packed(blob)
+  # The library copies on the legacy default stream, the collective runs on torch's own (non-blocking) RCCL
+  # stream: neither is ordered against the other, so fence on both sides of the broadcast (start-up only).
+  if on_gpu:
+    torch.cuda.synchronize(device)
   dist.broadcast(blob, src=src)
+  if on_gpu:
+    torch.cuda.synchronize(device)
   if not is_src:
     eng.import_packed(blob)
     model.adopt_engine(eng, height, width, flags)
