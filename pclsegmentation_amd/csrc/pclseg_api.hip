@@ -407,6 +407,16 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
 #define PCLSEG_UP_CFGS(X) X(4, 1, 8, 2, 1, 4) X(4, 1, 4, 1, 1, 2) X(4, 1, 2, 1, 1, 1) X(4, 1, 2, 0, 3, 1)
 hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStream_t s, const ConvArgs& a) {
   const int nq = op.fsq_fused ? a.fsq_q / 16 : 0;
+  // fire10 (64-channel up-convolved patch, 4 x 16-pixel tiles): the compile-time geometry K loop (conv_kernel GEOM 1) —
+  // with ONE cout tile per wave a K-step is only 12 MFMAs, so the generic loop's address arithmetic weighs most here
+  static const int geom_on = tune_env("PCLSEG_UP_GEOM", 1);
+  if (geom_on && op.mtw == 4 && op.ntw == 1 && op.wn == 8 && op.nw == 8 && nq == 2 && epi == 1 && op.cin_t == 64 &&
+      a.PW == 18 && a.PH == 6 && op.ck16 == 64) {
+    auto kfn = conv_kernel<4, 1, 8, false, true, 1, true, 8, 2, 4, 0, false, 1>;
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds)) return e;
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+  }
 #define PCLSEG_X(M_, N_, W_, Q_, E_, U_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == 8 && nq == Q_ && epi == E_ && op.cin_t == 16 * U_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_, U_>; \
