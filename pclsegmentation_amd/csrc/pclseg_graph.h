@@ -214,7 +214,8 @@ inline void op_geometry(Op* op) {
   // (Darknet-53 64x2048 / Darknet-21 32x1024 scans/s): 4-wave 334 / 2449, 128 couts 351 / 2578,
   // 256 couts where they divide 360 / 2657, the 1x1 layers too 364 / 2675.  (tuning aid: 0..3)
   static const int dn8 = tune_env("PCLSEG_DN8", 3);
-  if (dn8 && op->kind == OP_CONV && op->nsub == 1 && !op->pair && nct % 8 == 0 && (dn8 >= 3 || !op_is_flat(*op)) && op->sk_in < 0) {
+  static const int dn_up = tune_env("PCLSEG_DN_UP8", 1);   // the decoder's transposed convs (two parity sub-convs) too
+  if (dn8 && op->kind == OP_CONV && (op->nsub == 1 || (dn_up && op->nsub == 2 && op->sub[0].deconv)) && !op->pair && nct % 8 == 0 && (dn8 >= 3 || !op_is_flat(*op)) && op->sk_in < 0) {
     op->nw = 8; op->wn = 4; op->ntw = 2; op->mtw = 4;
     if (dn8 >= 2 && nct % 16 == 0) { op->wn = 8; op->mtw = 8; }   // 128 px x 256 couts
   }
