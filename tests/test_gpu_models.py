@@ -541,8 +541,9 @@ def test_fused_squeeze_intermediates(cuda, h, w):
 
 
 def test_fusion_is_active_by_default_and_off_for_debug_reads(cuda):
-  """The default SqueezeSegV2 plan launches 21 kernels per micro-batch (37 without the nine fused
-  squeezes, the three fused pools and the four fused up-convolutions); KEEP_ACTIVATIONS / exact-f32 / range-fallback plans keep the 37-launch graph."""
+  """The default SqueezeSegV2 plan launches 20 kernels per micro-batch (37 without the nine fused
+  squeezes, the three fused pools, the four fused up-convolutions and the fused fire13 + conv14 + head tail);
+  KEEP_ACTIVATIONS / exact-f32 / range-fallback plans keep the 37-launch graph."""
   mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
   d = E.make_desc("squeezesegv2", 32, 240, 11, 10, mc.INPUT_MEAN, mc.INPUT_STD)
   assert E.plan(d)["num_ops"] == 19           # + the normalise launch = 20
