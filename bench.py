@@ -459,7 +459,7 @@ def main():
       "config": {"workload": args.workload, "model": r["model_name"], "shape": [r["h"], r["w"]],
                  "num_class": mc.NUM_CLASS, "batch_per_gpu": r["batch"], "global_batch": r["global_batch"],
                  "math": "storage, accumulation and outputs float32; products on split-f16 operands (hi*hi + hi*lo + "
-                         "lo*hi on v_mfma_f32_16x16x32_f16): weights pre-scaled per output channel so every weight "
+                         "lo*hi on v_mfma_f32_16x16x32_f16): weights pre-scaled per 16-channel tile so every weight "
                          "keeps 22 bits, activations 22 bits where |v| >= 1/8 and an absolute 2^-25 below; measured "
                          "logit error in parity_check",
                  "micro_batch": r["info"]["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")),

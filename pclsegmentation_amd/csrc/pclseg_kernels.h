@@ -8,9 +8,11 @@
 // in a pre-packed per-lane fragment order.  Two arithmetic modes:
 //   F16X3 = false  v_mfma_f32_16x16x4_f32: exact float32 (bit-identical to an fmaf chain).
 //   F16X3 = true   v_mfma_f32_16x16x32_f16 on split operands: every float32 value v is carried
-//                  as hi = f16(v), lo = f16(v - hi) (22 significant bits) and a product is
-//                  hi*hi + hi*lo + lo*hi with float32 accumulation — float32-class accuracy
-//                  (|logit error| ~1e-5 through the whole network) at 3/16 of the f32 MFMA cost.
+//                  as hi = f16(v), lo = f16(v - hi) — 22 significant bits while lo is a normal half
+//                  (|v| >= 2^-3), an absolute 2^-25 below; weights are pre-scaled per 16-cout tile so
+//                  that all of them sit in the 22-bit regime (pclseg_api.hip: scale_exponent) — and a
+//                  product is hi*hi + hi*lo + lo*hi with float32 accumulation: float32-class accuracy
+//                  (|logit error| 1-4e-5 through the whole network) at 3/16 of the f32 MFMA cost.
 // One launch covers
 //   Conv2D 3x3 / 1x1, strides (1,1) and (1,2), TF "SAME" padding      (SURVEY.md K2,K3,K4)
 //   Conv2DTranspose (1,4)/(1,2): both output parities as two 2-tap sub-convs     (K5)
@@ -190,6 +192,8 @@ template <int NTW>
 __device__ __forceinline__ void head_finish(const f32x4 (&lv)[NTW], const bool valid, const size_t pix, const int g,
                                             const int NC, const uint8_t mask_px, int32_t* preds, float* probs,
                                             float* logits, const int none_index) {
+  // (written with selects, not per-element branches: `co < NC` differs per lane group, and every divergent
+  // `if` costs a saveexec / branch / restore triple in a kernel that is bound by instruction issue)
   float val[NTW * 4];
   float best = -INFINITY;
   int bi = 0;
@@ -199,19 +203,30 @@ __device__ __forceinline__ void head_finish(const f32x4 (&lv)[NTW], const bool v
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int co = nn * 16 + g * 4 + i;
-      const float v = lv[nn][i];
+      const bool in = co < NC;
+      const float v = in ? lv[nn][i] : -INFINITY;      // (classes beyond NC never win and never count as "bad")
       val[nn * 4 + i] = v;
-      if (co < NC) {
-        if (logits && valid) logits[pix * NC + co] = v;
-        bad = bad || !(v < INFINITY);   // NaN or +inf
-        if (v > best) { best = v; bi = co; }
-      }
+      bad = bad || (in && !(v < INFINITY));             // NaN or +inf
+      const bool up = v > best;
+      best = up ? v : best;
+      bi = up ? co : bi;
     }
+  if (logits) {   // (uniform)
+#pragma unroll
+    for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = nn * 16 + g * 4 + i;
+        if (valid && co < NC) logits[pix * NC + co] = lv[nn][i];
+      }
+  }
 #pragma unroll
   for (int off = 16; off <= 32; off <<= 1) {
     const float ov = __shfl_xor(best, off);
     const int oi = __shfl_xor(bi, off);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    const bool take = ov > best || (ov == best && oi < bi);
+    best = take ? ov : best;
+    bi = take ? oi : bi;
   }
   {
     int b = bad ? 1 : 0;
@@ -219,7 +234,7 @@ __device__ __forceinline__ void head_finish(const f32x4 (&lv)[NTW], const bool v
     b |= __shfl_xor(b, 32);
     bad = b != 0;
   }
-  if (probs) {
+  if (probs) {   // (uniform)
     // softmax materialised: exp(x - max) / sum, and the argmax is taken over the
     // probabilities exactly as the reference does (lowest index wins ties).
     float sum = 0.f;
@@ -1206,16 +1221,16 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   const f32x4 ub = *reinterpret_cast<const f32x4*>(a.up_bias + parity * 32 + g * 4);
   const float ui = sload(a.up_bias + parity * 32 + 16);
   // (3) the skip branch's raw-input addresses of this wave's 3 F segments
-  int uoff[3];
-  bool fvalid[3], fimg[3];
+  int uoff[3], foff[3];
+  bool fimg[3];
   const float* sxp[3];
   {
     const float* x8n = a.x8 + (size_t)n * a.H * a.W * 8;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       const int l = (wave * 3 + m) * 16 + p;
-      fvalid[m] = l < kFhFH * kFhFW;
-      const int lc = fvalid[m] ? l : kFhFH * kFhFW - 1;
+      const int lc = l < kFhFH * kFhFW ? l : kFhFH * kFhFW - 1;   // (lanes past the region repeat its last pixel)
+      foff[m] = lc * kFhCSF;
       const int r = lc / kFhFW, c = lc - r * kFhFW;
       uoff[m] = (r * kFhUW + c) * kFhCSU;
       const int h = h0 - 1 + r, w = w0 - 1 + c;
@@ -1248,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     const int oh = h0 + wave * 2 + m, ow = w0 + p;
     ovalid[m] = oh < a.H && ow < a.W;
     opix[m] = ((size_t)n * a.H + oh) * a.W + ow;
-    omask[m] = ovalid[m] ? a.mask[opix[m]] : (uint8_t)0;
+    omask[m] = a.mask[ovalid[m] ? opix[m] : (size_t)0];   // (clamped address instead of a branch; unused when !ovalid)
   }
 
   // ---------------------------------------------------------------- phase 0: patch and skip weights -> LDS
@@ -1269,8 +1284,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     for (int u0 = 0; u0 < UNITS; u0 += 2) {
       const int u = u0 + (wave >> 1);
       const int l = u * 16 + p;
-      const bool lv = l < PER;
-      const int lc = lv ? l : PER - 1;
+      const int lc = l < PER ? l : PER - 1;
       const int pr = lc / (kFhUW / 2), k2 = lc - pr * (kFhUW / 2);
       const int pc = 2 * k2 + parity;
       const int h = h0 - 2 + pr, w = w0 - 2 + pc;
@@ -1283,7 +1297,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
       au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwl, xh, au, 0, 0, 0);
       au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xl, au, 0, 0, 0);
       au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xh, au, 0, 0, 0);
-      if (lv) {
+      {   // (lanes past the last pixel were clamped onto it: they compute and store ITS value again — no branch)
         f32x4 v = fma4(au, ui, ub);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
@@ -1420,11 +1434,9 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
         vmax = absmax4(vmax, v);
         f16x4 hi, lo;
         split4(v, hi, lo);
-        if (fvalid[m]) {
-          _Float16* d = F + ((wave * 3 + m) * 16 + p) * kFhCSF + co;
-          *reinterpret_cast<f16x4*>(d) = hi;
-          *reinterpret_cast<f16x4*>(d + 64) = lo;
-        }
+        _Float16* d = F + foff[m] + co;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 64) = lo;
       }
     }
     asm volatile("" ::: "memory");
