@@ -540,6 +540,30 @@ def test_fused_squeeze_intermediates(cuda, h, w):
   assert r.stdout.count("/squeeze") == 12, r.stdout
 
 
+@pytest.mark.parametrize("config_name", ["squeezesegv2", "squeezesegv2kitti"])   # 11 classes: one head tile; 20: two
+@pytest.mark.parametrize("h,w", [(5, 16), (9, 48), (64, 16), (1, 32), (17, 80)])
+def test_fully_fused_plan_on_tiny_and_ragged_shapes(cuda, config_name, h, w):
+  """The default (fully fused, 19-launch) plan on shapes where every tile of every fused kernel overhangs the
+  image: a single 16-pixel tile column, fewer rows than a tile, one row — logits, probabilities, class IDs and
+  the None class of masked pixels against the float64 oracle."""
+  mc, model = P.load_model_config("squeezesegv2", config_name, height=h, width=w)
+  model.init_weights(4321)
+  raw = synthetic_scans(3, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.8, seed=h * 100 + w)
+  eng = model.engine(h, w)
+  assert E.plan(eng.desc)["num_ops"] == 19
+  preds = np.empty((3, h, w), np.int32)
+  logits = np.empty((3, h, w, mc.NUM_CLASS), np.float32)
+  probs = np.empty_like(logits)
+  eng.forward_raw(raw, 3, preds, probs, logits, None, mem=E.MEM_HOST)
+  lidar, mask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
+  none_index = mc.CLASSES.index("None")
+  _, opred, ologits = O.forward("squeezesegv2", model.weights, lidar, mask, none_index, dtype=np.float64)
+  srt = np.sort(ologits, -1)
+  check_against(preds, logits, mask, ologits, opred, srt[..., -1] - srt[..., -2], none_index)
+  assert np.allclose(probs.sum(-1), 1.0, atol=1e-5)
+  model._drop_engines()
+
+
 def test_fusion_is_active_by_default_and_off_for_debug_reads(cuda):
   """The default SqueezeSegV2 plan launches 20 kernels per micro-batch (37 without the nine fused
   squeezes, the three fused pools, the four fused up-convolutions and the fused fire13 + conv14 + head tail);
