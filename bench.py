@@ -406,9 +406,11 @@ def main():
   dev = torch.device("cuda", dev_index)
   stream = torch.cuda.current_stream(dev)
 
+  coll = D.collectives_active()   # > 1 rank, or a forced one-rank group (PCLSEG_FORCE_COLLECTIVES=1: test aid)
+
   def fence():
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if coll:
       torch.distributed.barrier()
     torch.cuda.synchronize(dev)
 
@@ -431,7 +433,7 @@ def main():
     preds = torch.empty((batch, h, w), dtype=torch.int32, device=dev)
     elapsed, dev_ms = time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence)
     eng.sync()   # also reports a split-f16 range overflow (PCLSEG_ERR_RANGE) instead of timing garbage
-    if world > 1:
+    if coll:
       red_dev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
       t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=red_dev)
       torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # MAX over ranks
@@ -466,6 +468,9 @@ def main():
                  "parallelism": "batch-sharded x%d (%s scaling, weights folded+packed once and broadcast)" % (world, args.scaling)},
       "roofline": roof,
     }
+    if coll:
+      out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
+                                      "timing_reduced_on": "device" if torch.distributed.get_backend() == "nccl" else "host"}
     if os.environ.get("PCLSEG_DIST_BACKEND") == "gloo" and world > 1:
       out["config"]["note"] = "ranks share GPUs (fewer devices than ranks): functional check, not a scaling run"
   if world == 1 and not args.no_secondary:
@@ -540,7 +545,7 @@ def main():
       out["cpu_baseline"] = cpu_baseline(r["model_name"], r["mc"], r["weights"], r["h"], r["w"], r["pvalid"],
                                          args.cpu_seconds)
     print(json.dumps(out), flush=True)
-  if world > 1:
+  if coll:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -11,6 +11,10 @@ therefore pinned only by (i) the hand-computed known-answer vectors of SURVEY.md
 Appendix E (tests/test_oracle_kat.py), (ii) an independent PyTorch-CPU expression of
 the same graph (oracle/torch_ref.py) and (iii) fixtures generated from itself.  TF was
 never executed; a mis-read TF convention would go undetected.
+PINNED BY THE REFERENCE ITSELF (its own NumPy code run in the build container, outputs committed as
+fixtures): the pre-processing row — normalize_and_mask / parse_sample against DataLoader.parse_sample
+(tests/golden/preproc_*.npz) — the spherical projections (tests/golden/projection*.npz) and the config
+constants (tests/golden/configs.json).
 
 Every function cites the reference lines it follows.  ``dtype`` selects float64 (the
 reference arithmetic at higher precision, used as ground truth) or float32.
@@ -44,6 +48,24 @@ def normalize_and_mask(raw, mean, std):
   lidar[~mask] = 0.0
   lidar = np.concatenate([lidar, mask[..., None].astype(lidar.dtype)], axis=-1)
   return lidar, mask
+
+
+def parse_sample(sample, mean, std, none_index, cls_loss_weight=None):
+  """reference: data_loader/data_loader.py:138-187 (DataLoader.parse_sample) and the same steps of
+  inference.py:47-66 / eval.py's loop: the file content [..., H, W, 6] is cast to float32, normalised and
+  masked (normalize_and_mask), and the label channel gets the "None" class wherever the mask is False
+  (:176-180; inference.py:65-66).  Returns what parse_sample returns: lidar float32 [...,H,W,6], mask bool,
+  label int32, weight float32 (class-wise loss weights, :182-185; zeros when no table is given).
+  PINNED by tests/golden/preproc_*.npz, which are outputs of the reference function itself."""
+  sample = np.asarray(sample).astype(np.float32)
+  lidar, mask = normalize_and_mask(sample, mean, std)
+  label = sample[..., 5].copy()
+  label[~mask] = none_index
+  weight = np.zeros(label.shape)
+  if cls_loss_weight is not None:
+    for l, wl in enumerate(np.asarray(cls_loss_weight).ravel()):
+      weight[label == l] = wl
+  return lidar.astype(np.float32), mask, label.astype(np.int32), weight.astype(np.float32)
 
 
 def conv2d(x, kernel, bias=None, stride_w=1):

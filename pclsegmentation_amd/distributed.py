@@ -19,11 +19,24 @@ def env_world():
           int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def force_collectives():
+  """PCLSEG_FORCE_COLLECTIVES=1 (test aid): a ONE-rank job still initialises the process group and runs
+  every collective of the multi-GPU path — the status / packed-parameter broadcasts of broadcast_engine, the
+  import of the broadcast blob into a fresh handle, bench.py's all_reduce of the timings — so the RCCL code
+  path executes on a box with a single MI355X (tests/test_gpu_distributed.py)."""
+  return os.environ.get("PCLSEG_FORCE_COLLECTIVES") == "1"
+
+
+def collectives_active():
+  """True when this job runs the multi-GPU code path: more than one rank, or a forced one-rank group."""
+  return dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives())
+
+
 def init_process_group(backend=None):
   """Initialise torch.distributed from MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE.
   backend defaults to nccl (= RCCL on ROCm) when a GPU is visible, else gloo."""
   rank, local_rank, world = env_world()
-  if world > 1 and not dist.is_initialized():
+  if (world > 1 or (force_collectives() and "MASTER_PORT" in os.environ)) and not dist.is_initialized():
     bind_rank(local_rank)            # (sysfs + sched_setaffinity only; nothing below has touched HIP yet)
     if backend is None:   # PCLSEG_DIST_BACKEND=gloo: test aid (several ranks sharing one GPU)
       backend = os.environ.get("PCLSEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -61,7 +74,7 @@ def unpack_weights(spec, flat):
 def broadcast_weights(spec, weights, src=0, device=None):
   """One broadcast of the packed weight blob (3.75 MB SqueezeSegV2 ... 212 MB Darknet-53).
   ``weights`` is only read on rank ``src``; every rank returns the full dict."""
-  if not dist.is_initialized() or dist.get_world_size() == 1:
+  if not collectives_active():
     return weights
   n = sum(int(np.prod(w.shape)) for w in spec)
   if dist.get_backend() != "nccl":
@@ -81,18 +94,48 @@ def broadcast_engine(model, height, width, flags=0, src=0, device=None):
   weights.  Rank ``src`` folds BatchNorm and packs the MFMA fragments once (pclseg_finalize), exports
   the packed device arrays into one buffer (pclseg_export_packed), ONE broadcast moves it — over
   RCCL/xGMI device to device — and the other ranks import it (pclseg_import_packed: a device copy).
-  Darknet-53: one 216 MB collective instead of eight host-side fold + repack passes of 53 M parameters."""
+  Darknet-53: one 216 MB collective instead of eight host-side fold + repack passes of 53 M parameters.
+
+  A 16-byte status broadcast goes first: if rank ``src`` cannot build its engine (no weights bound,
+  pclseg_finalize refusing non-finite folded weights, out of memory) EVERY rank raises, instead of the
+  other ranks waiting in the blob's collective until the RCCL / gloo timeout.
+
+  With PCLSEG_FORCE_COLLECTIVES=1 a one-rank group runs the same sequence and returns the engine that
+  IMPORTED the broadcast blob (the source engine is dropped), so a single-GPU box executes the transport."""
   from . import engine as _engine
-  if not dist.is_initialized() or dist.get_world_size() == 1:
+  if not collectives_active():
     return model.engine(height, width, flags)
   on_gpu = dist.get_backend() == "nccl"
-  if on_gpu and device is None:
-    device = torch.device("cuda", torch.cuda.current_device())
-  if not on_gpu:
+  if on_gpu:
+    want = torch.device("cuda", int(model.device))
+    if device is not None and torch.device(device) != want:
+      raise ValueError("broadcast_engine: model.device is %s but the blob was asked for on %s" % (want, device))
+    device = want
+    torch.cuda.set_device(device)   # RCCL binds a rank's communicator to the current device
+  else:
     device = torch.device("cpu")     # gloo moves host tensors (ranks sharing one GPU in tests)
   is_src = dist.get_rank() == src
-  eng = model.engine(height, width, flags) if is_src else _engine.Engine(model.engine_desc(height, width, flags))
-  blob = torch.empty(eng.packed_size(), dtype=torch.uint8, device=device)
+  loopback = dist.get_world_size() == 1
+  eng, err = None, None
+  status = torch.zeros(2, dtype=torch.int64, device=device)      # [ok, packed bytes]
+  if is_src:
+    try:
+      eng = model.engine(height, width, flags)
+      status[0], status[1] = 1, eng.packed_size()
+    except Exception as e:      # reported to every rank below, then re-raised here
+      err = e
+  dist.broadcast(status, src=src)
+  ok, nbytes = int(status[0].item()), int(status[1].item())
+  if not ok:
+    if err is not None:
+      raise err
+    raise RuntimeError("broadcast_engine: rank %d could not build the engine (see its log)" % src)
+  if not is_src or loopback:
+    dst = _engine.Engine(model.engine_desc(height, width, flags))
+    if dst.packed_size() != nbytes:
+      raise RuntimeError("broadcast_engine: rank %d packs %d bytes, this rank's plan needs %d "
+                         "(different library builds or fusion switches between ranks?)" % (src, nbytes, dst.packed_size()))
+  blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
   if is_src:
     eng.export_packed(blob)
   # The library copies on the legacy default stream, the collective runs on torch's own (non-blocking) RCCL
@@ -102,9 +145,12 @@ def broadcast_engine(model, height, width, flags=0, src=0, device=None):
   dist.broadcast(blob, src=src)
   if on_gpu:
     torch.cuda.synchronize(device)
-  if not is_src:
-    eng.import_packed(blob)
-    model.adopt_engine(eng, height, width, flags)
+  if not is_src or loopback:
+    dst.import_packed(blob)
+    if loopback:
+      model._drop_engines()          # the returned engine is the one that came through the collective
+    model.adopt_engine(dst, height, width, flags)
+    eng = dst
   return eng
 
 
@@ -145,7 +191,7 @@ def bind_rank(local_rank):
 def gather_predictions(local_preds, n_total, dst=0):
   """Optional: collect every rank's int32 predictions [n_local,H,W] on rank ``dst`` in scan
   order (ranks may hold different counts)."""
-  if not dist.is_initialized() or dist.get_world_size() == 1:
+  if not collectives_active():
     return local_preds
   world, rank = dist.get_world_size(), dist.get_rank()
   counts = [shard_range(n_total, r, world) for r in range(world)]

@@ -87,6 +87,15 @@ class MeanIoU:
     return float(np.where(valid, tp / np.where(valid, denom, 1), 0.0).sum() / valid.sum())
 
 
+def masked_labels(samples, mask, none_index):
+  """The reference's ``label[~mask] = config.CLASSES.index("None")`` (eval.py / inference.py:65-66,
+  data_loader/data_loader.py:176-180) on the device: samples [N,H,W,6] float32 (channel 5 = label),
+  mask [N,H,W] uint8/bool -> int32 labels [N,H,W]."""
+  import torch
+  none = torch.tensor(none_index, dtype=torch.int32, device=samples.device)
+  return torch.where(mask.bool(), samples[..., 5].to(torch.int32), none)
+
+
 def evaluation(arg):
   if arg.path_to_model:
     model = load_model(arg.path_to_model, model_name=arg.model, config_name=arg.config)   # .npz or SavedModel dir
@@ -105,7 +114,7 @@ def evaluation(arg):
   for b0 in range(0, len(files), arg.batch):
     samples = torch.from_numpy(np.stack([np.load(f).astype(np.float32) for f in files[b0:b0 + arg.batch]])).to(dev)
     predictions, mask = model.predict_raw(samples[..., :5], return_mask=True)       # device tensors
-    label = torch.where(mask.bool(), samples[..., 5].to(torch.int32), torch.tensor(none_index, dtype=torch.int32, device=dev))
+    label = masked_labels(samples, mask, none_index)
     miou_tracker.update_state(label, predictions)
   if miou_tracker.ignored:
     print("warning: %d pixels carry a label outside [0, %d) and were not counted"

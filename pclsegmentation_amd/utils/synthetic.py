@@ -22,3 +22,16 @@ def synthetic_scans(n, h, w, mean, std, p_valid=0.78, seed=1234):
   scans = np.concatenate([feat, depth[..., None]], axis=-1)
   scans[~valid] = 0.0
   return scans.astype(np.float32)
+
+
+def synthetic_scan_range(lo, hi, h, w, mean, std, p_valid=0.78, seed=1234, chunk=8):
+  """Scans [lo, hi) of ONE seeded job batch of any length, generated in chunks of ``chunk`` scans
+  (chunk c is ``synthetic_scans(chunk, ..., seed=seed + c)``): a rank of a sharded job materialises only
+  the scans it owns, and every rank — and the single-process check — sees the same scan i."""
+  if hi <= lo:
+    return np.zeros((0, h, w, 5), np.float32)
+  parts = []
+  for c in range(lo // chunk, (hi - 1) // chunk + 1):
+    s = synthetic_scans(chunk, h, w, mean, std, p_valid, seed=seed + c)
+    parts.append(s[max(lo - c * chunk, 0):min(hi - c * chunk, chunk)])
+  return np.concatenate(parts, axis=0)

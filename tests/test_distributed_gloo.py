@@ -70,6 +70,68 @@ def test_two_process_broadcast_and_sharding():
   assert res[0][3] == [0, 10, 20, 31, 41] and res[1][3] is None
 
 
+def _failing_src_worker(rank, world, port, q):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                    LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+  import pclsegmentation_amd as P
+  D.init_process_group(backend="gloo")
+  _, model = P.load_model_config("squeezesegv2", "squeezesegv2")     # NO weights bound on any rank
+  try:
+    D.broadcast_engine(model, 32, 240, src=0)
+    q.put((rank, "returned"))
+  except RuntimeError as e:
+    q.put((rank, "RuntimeError: %s" % e))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_broadcast_engine_failure_on_the_source_rank_raises_everywhere():
+  """Rank 0 cannot build its engine (no weights): the status broadcast that precedes the blob makes rank 1
+  raise too, instead of waiting in a collective that rank 0 never joins."""
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_failing_src_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = dict(q.get(timeout=120) for _ in range(2))
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0
+  assert "no weights" in res[0] and res[0].startswith("RuntimeError")
+  assert "rank 0 could not build the engine" in res[1]
+
+
+def _one_rank_worker(port, q):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                    PCLSEG_FORCE_COLLECTIVES="1")
+  r, _, ws = D.init_process_group(backend="gloo")
+  ok = dist.is_initialized() and D.collectives_active() and (r, ws) == (0, 1)
+  spec = squeezesegv2_spec(11)
+  w = D.broadcast_weights(spec, synthetic_weights(spec, 1), src=0)
+  full = D.gather_predictions(torch.arange(6, dtype=torch.int32).view(3, 2, 1), 3, dst=0)
+  q.put((ok, len(w), full[:, 0, 0].tolist()))
+  dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_runs_the_collectives():
+  """PCLSEG_FORCE_COLLECTIVES=1: a one-rank job initialises the group and goes through the collectives
+  (the switch behind the one-rank RCCL test on the GPU box)."""
+  assert not D.collectives_active()
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = ctx.Process(target=_one_rank_worker, args=(port, q))
+  p.start()
+  ok, nw, first = q.get(timeout=120)
+  p.join(60)
+  assert p.exitcode == 0 and ok and nw == len(squeezesegv2_spec(11)) and first == [0, 2, 4]
+
+
 def test_rank_binding_and_gpu_census_never_touch_hip():
   """bench.py's launcher and distributed.bind_rank decide from sysfs / the environment only; both must
   work (and do nothing harmful) on a box without a GPU."""

@@ -16,7 +16,7 @@ import pytest
 import pclsegmentation_amd as P
 from pclsegmentation_amd import distributed as D
 from pclsegmentation_amd import engine as E
-from pclsegmentation_amd.utils.synthetic import synthetic_scans
+from pclsegmentation_amd.utils.synthetic import synthetic_scan_range, synthetic_scans
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +47,7 @@ def test_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path, world,
   # single-process reference on this process's engine
   mc, model = P.load_model_config("squeezesegv2", "squeezesegv2", height=h, width=w)
   model.init_weights(4321)
-  raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=99)
+  raw = synthetic_scan_range(0, n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=99)
   eng = model.engine(h, w)
   preds = np.empty((n, h, w), np.int32)
   logits = np.empty((n, h, w, mc.NUM_CLASS), np.float32)
@@ -61,6 +61,98 @@ def test_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path, world,
     seen[lo:hi] = True
   assert seen.all()
   assert np.array_equal(np.load(str(tmp_path / "gathered.npy")), preds)   # optional gather, scan order
+
+
+def _torchrun(world, script_args, env, timeout=900):
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+  return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_one_rank_nccl_runs_the_rccl_transport(cuda, tmp_path):
+  """The RCCL code path on the one GPU this box has: ONE rank under torch.distributed.run with the nccl
+  backend and PCLSEG_FORCE_COLLECTIVES=1 — init_process_group's nccl branch, broadcast_engine's status
+  broadcast, export -> dist.broadcast(device uint8 blob) -> pclseg_import_packed(MEM_DEVICE) into a fresh
+  handle, a forward pass on THAT handle, all_gather of device predictions and an all_reduce of a device
+  tensor.  Outputs must be bit-identical to the plain engine's.  What stays unexercised is the xGMI wire."""
+  h, w, n = 32, 240, 5
+  env = _rank_env()
+  env.pop("PCLSEG_DIST_BACKEND")
+  env["PCLSEG_FORCE_COLLECTIVES"] = "1"
+  r = _torchrun(1, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(n), str(h), str(w)], env, 600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  g = np.load(str(tmp_path / "rank0.npz"))
+  assert str(g["backend"]) == "nccl" and int(g["world"]) == 1 and bool(g["engine_came_through_collective"])
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2", height=h, width=w)
+  model.init_weights(4321)
+  raw = synthetic_scan_range(0, n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=99)
+  preds = np.empty((n, h, w), np.int32)
+  logits = np.empty((n, h, w, mc.NUM_CLASS), np.float32)
+  model.engine(h, w).forward_raw(raw, n, preds, None, logits, None, mem=E.MEM_HOST)
+  assert np.array_equal(g["preds"], preds) and np.array_equal(g["logits"], logits)
+  assert np.array_equal(np.load(str(tmp_path / "gathered.npy")), preds)
+  model._drop_engines()
+
+
+def test_bench_one_rank_nccl_reduces_its_timings_on_the_device(cuda):
+  """bench.py as the driver launches it for N > 1 (under torch.distributed.run), here with one forced rank:
+  nccl process group, broadcast_engine through RCCL, barrier-fenced timed region, all_reduce(MAX) of the
+  timing tensor ON THE DEVICE (bench.py's multi-GPU branch)."""
+  env = _rank_env()
+  env.pop("PCLSEG_DIST_BACKEND")
+  env["PCLSEG_FORCE_COLLECTIVES"] = "1"
+  r = _torchrun(1, [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                    "--workload", "ssv2_32x240", "--cpu-seconds", "0", "--no-secondary"], env)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+  assert out["config"]["collectives"] == {"backend": "nccl", "world": 1, "timing_reduced_on": "device"}
+  assert out["value"] > 0 and out["n_gpus"] == 1
+
+
+def test_c4_full_size_256_scans_over_8_ranks(cuda, tmp_path):
+  """BASELINE configs[3] (C4) functionally: 256 scans of 64x2048 (SqueezeSegV2, 20 classes) sharded over 8
+  fresh rank processes — 32 scans each, one packed-parameter broadcast, no data-path collective.  The ranks
+  share this box's one MI355X and rendezvous over gloo; every rank's predictions (and the logits of its
+  first scan) must equal the single-process result for shard_range(256, r, 8)."""
+  h, w, n, world = 64, 2048, 256, 8
+  r = _torchrun(world, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(n), str(h), str(w),
+                        "squeezesegv2kitti"], _rank_env(), 1500)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2kitti", height=h, width=w)
+  model.init_weights(4321)
+  eng = model.engine(h, w)
+  covered = 0
+  for rank in range(world):
+    g = np.load(str(tmp_path / ("rank%d.npz" % rank)))
+    lo, hi = int(g["lo"]), int(g["hi"])
+    assert (lo, hi) == D.shard_range(n, rank, world) == (32 * rank, 32 * rank + 32)
+    raw = synthetic_scan_range(lo, hi, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.78, seed=99)
+    preds = np.empty((hi - lo, h, w), np.int32)
+    eng.forward_raw(raw, hi - lo, preds, None, None, None, mem=E.MEM_HOST)
+    assert np.array_equal(g["preds"], preds), "rank %d" % rank
+    first, logits = np.empty((1, h, w), np.int32), np.empty((1, h, w, mc.NUM_CLASS), np.float32)
+    eng.forward_raw(raw, 1, first, None, logits, None, mem=E.MEM_HOST)
+    assert np.array_equal(g["logits"], logits) and np.array_equal(first[0], preds[0])
+    assert len(np.unique(preds)) > 3          # not a degenerate map
+    covered += hi - lo
+  assert covered == n
+  model._drop_engines()
+
+
+def test_bench_c4_strong_scaling_full_size(cuda):
+  """`bench.py --gpus 8 --scaling strong --global-batch 256` at the headline shape: the driver's C4 command
+  line, with the 8 ranks sharing one GPU (functional check of the launch, sharding and reduction)."""
+  env = _rank_env()
+  env.pop("PCLSEG_DIST_BACKEND")
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+         "--cpu-seconds", "0", "--scaling", "strong", "--global-batch", "256"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+  assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+  assert out["config"]["workload"] == "ssv2_64x2048" and out["config"]["shape"] == [64, 2048]
+  assert out["config"]["global_batch"] == 256 and out["config"]["batch_per_gpu"] == 32
+  assert out["config"]["collectives"]["backend"] == "gloo" and out["value"] > 0
 
 
 def test_bench_launches_its_own_ranks(cuda):
