@@ -3,20 +3,25 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := pclsegmentation_amd/csrc
 LIB   := pclsegmentation_amd/libpclseg.so
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function
+SRCS  := $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h $(CSRC)/pclseg_api.hip include/pclseg.h
+# sha256 over the sources, in the order bench.py's csrc_sha() reads them, baked into the library
+# (pclseg_build_sha): bench.py compares it with the sources next to it and refuses to quote a PMC
+# traffic figure when the binary that ran was built from something else
+SRC_SHA := $(shell cat $(SRCS) | sha256sum | cut -c1-16)
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -DPCLSEG_SRC_SHA=\"$(SRC_SHA)\"
 
 all: $(LIB)
 
-$(LIB): $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
+$(LIB): $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/pclseg_api.hip
 
 # debug build with in-kernel phase timestamps (PCLSEG_STAMP=<layer> PCLSEG_LIB=.../libpclseg_stamps.so)
-stamps: $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
+stamps: $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -DPCLSEG_WITH_STAMPS -o pclsegmentation_amd/libpclseg_stamps.so $(CSRC)/pclseg_api.hip
 
 # A/B build: the experiment switches of DESIGN.md §9/§10 (PCLSEG_GEOM, PCLSEG_DN8, ...) are read from the
 # environment (PCLSEG_LIB=.../libpclseg_tuning.so); the shipped library carries only their defaults
-tuning: $(CSRC)/pclseg_api.hip $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h include/pclseg.h
+tuning: $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -DPCLSEG_TUNING -o pclsegmentation_amd/libpclseg_tuning.so $(CSRC)/pclseg_api.hip
 
 clean:

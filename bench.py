@@ -257,21 +257,25 @@ def build_engine(P, D, synthetic_weights, workload, dev_index, dev, rank, micro_
   return mc, model, eng, weights, (batch or wl_batch)
 
 
-def time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence):
-  """-> (wall seconds, device milliseconds) of `steps` forward_raw calls, fenced on both sides."""
+def time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence, repeats=1):
+  """-> [(wall seconds, device milliseconds)] x repeats, each of EXACTLY `steps` forward_raw calls fenced
+  (barrier + device synchronise) on both sides; `warmup` untimed steps before the first region."""
   def step():
     eng.forward_raw(scans, batch, preds, None, None, None, mem=E.MEM_DEVICE)
   for _ in range(warmup):
     step()
-  fence()
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record(stream)
-  for _ in range(steps):
-    step()
-  ev1.record(stream)
-  fence()
-  return time.perf_counter() - t0, ev0.elapsed_time(ev1)      # HIP events on the engine's stream
+  out = []
+  for _ in range(repeats):
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(steps):
+      step()
+    ev1.record(stream)
+    fence()
+    out.append((time.perf_counter() - t0, ev0.elapsed_time(ev1)))      # HIP events on the engine's stream
+  return out
 
 
 def roofline_of(bound, scans_per_s_dev, info):
@@ -297,7 +301,8 @@ def roofline_of(bound, scans_per_s_dev, info):
   return roof
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_JSON = os.environ.get("PCLSEG_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r04_traffic.json")
+REPEATS = 5       # the timed region (K steps, fenced) is measured this many times: `value` = median, `spread` = [min, max]
 
 
 def attach_traffic(roof, workload, scans_per_s_dev, info):
@@ -311,13 +316,19 @@ def attach_traffic(roof, workload, scans_per_s_dev, info):
   w = t.get("workloads", {}).get(workload)
   if not w:
     return
+  from pclsegmentation_amd import engine as E
+  name = os.path.relpath(TRAFFIC_JSON, ROOT)
+  if E.build_sha() != csrc_sha():
+    roof["traffic_note"] = ("the loaded libpclseg.so was built from sources with sha %s, the sources beside it hash to %s: "
+                            "no profile figure is attributed to this binary" % (E.build_sha(), csrc_sha()))
+    return
   if t.get("csrc_sha") != csrc_sha():
-    roof["traffic_note"] = ("profiles/r03_traffic.json was measured on csrc sha %s, this build is %s: stale "
-                            "figure withheld" % (t.get("csrc_sha"), csrc_sha()))
+    roof["traffic_note"] = ("%s was measured on csrc sha %s, this build is %s: stale "
+                            "figure withheld" % (name, t.get("csrc_sha"), csrc_sha()))
     return
   roof["traffic"] = int(w["hbm_bytes_per_scan"])
   roof["traffic_unit"] = ("HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
-                          "profiles/r03_traffic.json, csrc sha %s" % t["csrc_sha"])
+                          "%s, csrc sha %s = pclseg_build_sha() of the binary that ran" % (name, t["csrc_sha"]))
   roof["physical"] = {
     "hbm_frac": round(w["hbm_bytes_per_scan"] * scans_per_s_dev / (HBM_PEAK_GBS * 1e9), 4),
     "mfma_frac": round(3 * 2 * info["alg_macs_per_scan"] * scans_per_s_dev / (F16_MFMA_PEAK_TF * 1e12), 4),
@@ -360,6 +371,58 @@ def parity_check(P, E, synthetic_weights, synthetic_scans, workload, dev, dev_in
     out["masked_are_none_" + key] = bool((pr[~omask[0]] == none_index).all())
     model._drop_engines()
   out["decided_identical"] = out["decided_identical_f16x3"] and out["decided_identical_f32"]
+  return out
+
+
+def c1_gpu_leg(P, E, synthetic_weights, dev_index):
+  """BASELINE.json configs[0] (C1) on the GPU, in the reference's own loop shape (inference.py:44-75): the 32
+  real 32x240 scans of dataset_samples/sample_dataset/train (committed fixture), ONE scan per call, host
+  buffers in and out, every call synchronous (PCLSEG_MEM_HOST) — what a drop-in user of inference.py sees per
+  file, next to cpu_baseline.legs.c1_real_32x240_batch1_*.  At this size a call is `launches_per_scan` kernel
+  launches of a few microseconds each: the figure is launch/round-trip latency, not throughput."""
+  real = os.path.join(ROOT, "tests", "golden", "c1_sample_dataset_train_32x240.npz")
+  if not os.path.exists(real):
+    return None
+  import torch
+  mc1, m1 = P.load_model_config("squeezesegv2", "squeezesegv2", device=dev_index)
+  m1.set_weights(synthetic_weights(m1.weight_spec(), 4321))
+  raw = np.ascontiguousarray(np.load(real)["raw"], dtype=np.float32)     # [32, 32, 240, 5]
+  n, h, w, _ = raw.shape
+  eng = m1.engine(h, w)
+  info = E.plan(eng.desc)
+
+  def loop(scans, preds, passes):
+    times = []
+    for _ in range(passes):
+      t0 = time.perf_counter()
+      for i in range(n):
+        eng.forward_raw(scans[i:i + 1], 1, preds[i:i + 1], None, None, None, mem=E.MEM_HOST)
+      times.append(time.perf_counter() - t0)
+    return sorted(times)[len(times) // 2]
+
+  preds = np.empty((n, h, w), np.int32)
+  loop(raw, preds, 2)
+  t_page = loop(raw, preds, 7)
+  p_raw = torch.from_numpy(raw).pin_memory()
+  p_preds = torch.empty((n, h, w), dtype=torch.int32).pin_memory()
+  loop(p_raw, p_preds, 2)
+  t_pin = loop(p_raw, p_preds, 7)
+  same = bool(np.array_equal(p_preds.numpy(), preds))
+  b_preds = np.empty((n, h, w), np.int32)
+  eng.forward_raw(raw, n, b_preds, None, None, None, mem=E.MEM_HOST)
+  t0 = time.perf_counter()
+  for _ in range(5):
+    eng.forward_raw(raw, n, b_preds, None, None, None, mem=E.MEM_HOST)
+  t_batch = (time.perf_counter() - t0) / 5
+  out = {"value": round(n / t_page, 1), "unit": "scans/s", "us_per_scan": round(1e6 * t_page / n, 1),
+         "launches_per_scan": info["num_ops"] + 1,
+         "sample": "the 32 real 32x240 scans of the reference's sample_dataset/train, batch 1, synchronous PCLSEG_MEM_HOST calls "
+                   "on pageable NumPy buffers (median of 7 passes): the reference's loop, inference.py:44-75",
+         "page_locked": {"value": round(n / t_pin, 1), "us_per_scan": round(1e6 * t_pin / n, 1)},
+         "one_call_batch32": {"value": round(n / t_batch, 1), "us_per_scan": round(1e6 * t_batch / n, 1),
+                              "identical_to_batch1": bool(np.array_equal(b_preds, preds))},
+         "page_locked_identical": same}
+  m1._drop_engines()
   return out
 
 
@@ -414,8 +477,9 @@ def main():
       torch.distributed.barrier()
     torch.cuda.synchronize(dev)
 
-  def run_workload(workload, steps, warmup, flags=0, batch=0):
-    """Build the engine of `workload`, time `steps` steps; -> dict for rank 0 (None elsewhere)."""
+  def run_workload(workload, steps, warmup, flags=0, batch=0, repeats=1):
+    """Build the engine of `workload`, time `steps` steps (`repeats` fenced regions of `steps` steps each, every
+    region reduced with MAX over the ranks; the MEDIAN region is reported); -> dict."""
     model_name, config_name, h, w, _, pvalid, bound = WORKLOADS[workload]
     mc, model, eng, weights, batch = build_engine(P, D, synthetic_weights, workload, dev_index, dev, rank,
                                                   args.micro_batch, flags, batch)
@@ -431,22 +495,25 @@ def main():
     scans = torch.from_numpy(synthetic_scans(batch, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pvalid,
                                              seed=1234 + rank)).to(dev)
     preds = torch.empty((batch, h, w), dtype=torch.int32, device=dev)
-    elapsed, dev_ms = time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence)
+    regions = time_steps(torch, eng, E, scans, preds, batch, stream, steps, warmup, fence, repeats)
     eng.sync()   # also reports a split-f16 range overflow (PCLSEG_ERR_RANGE) instead of timing garbage
     if coll:
       red_dev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
-      t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=red_dev)
-      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # MAX over ranks
-      elapsed, dev_ms = float(t[0]), float(t[1])
+      t = torch.tensor(regions, dtype=torch.float64, device=red_dev)
+      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # MAX over ranks, per region
+      regions = [(float(a), float(b)) for a, b in t.cpu().tolist()]
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, dev_ms = regions[order[len(order) // 2]]                      # the median region
     res = {"mc": mc, "model": model, "eng": eng, "weights": weights, "info": info, "batch": batch,
            "global_batch": global_batch,
            "scans": scans, "preds": preds, "elapsed": elapsed, "dev_ms": dev_ms, "h": h, "w": w,
            "pvalid": pvalid, "bound": bound, "model_name": model_name,
            "scans_per_s": global_batch * steps / elapsed,
-           "dev_scans_per_s": batch * steps / (dev_ms * 1e-3)}
+           "dev_scans_per_s": batch * steps / (dev_ms * 1e-3),
+           "region_scans_per_s": [round(global_batch * steps / r[0], 2) for r in regions]}
     return res
 
-  r = run_workload(args.workload, args.steps, args.warmup, batch=args.batch)
+  r = run_workload(args.workload, args.steps, args.warmup, batch=args.batch, repeats=REPEATS)
   if rank == 0:
     roof = roofline_of(r["bound"], r["dev_scans_per_s"], r["info"])
     attach_traffic(roof, args.workload, r["dev_scans_per_s"], r["info"])
@@ -456,6 +523,10 @@ def main():
                 else "LiDAR scans/sec %s inference" % args.workload,
       "value": round(r["scans_per_s"], 2), "unit": "scans/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": round(1e3 * r["elapsed"] / args.steps, 3),
+      "spread": [min(r["region_scans_per_s"]), max(r["region_scans_per_s"])],
+      "repeats": {"regions": REPEATS, "steps_each": args.steps, "scans_per_s": r["region_scans_per_s"],
+                  "note": "the timed region of exactly --steps steps (barrier + synchronise on both sides, MAX over ranks) "
+                          "is measured %d times back to back after ONE warm-up; value / ms_per_step = the median region" % REPEATS},
       "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
       "dtype": "f32 (f16x3 products)", "data": "synthetic",
       "config": {"workload": args.workload, "model": r["model_name"], "shape": [r["h"], r["w"]],
@@ -467,6 +538,7 @@ def main():
                  "micro_batch": r["info"]["micro_batch"], "lanes": int(os.environ.get("PCLSEG_LANES", "3")),
                  "parallelism": "batch-sharded x%d (%s scaling, weights folded+packed once and broadcast)" % (world, args.scaling)},
       "roofline": roof,
+      "build": {"binary_sha": E.build_sha(), "sources_sha": csrc_sha(), "binary_matches_sources": E.build_sha() == csrc_sha()},
     }
     if coll:
       out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
@@ -537,6 +609,10 @@ def main():
         "batch": y["batch"], "ms_per_step": round(1e3 * y["elapsed"] / st, 3), "roofline": roof_y})
       y["model"]._drop_engines()
       del y
+    # ---- BASELINE configs[0] in the reference's loop shape, on the GPU
+    c1 = c1_gpu_leg(P, E, synthetic_weights, dev_index)
+    if c1:
+      out["c1_gpu"] = c1
     # ---- parity evidence of this very build, outside every timed region
     out["parity_check"] = [parity_check(P, E, synthetic_weights, synthetic_scans, wl, dev, dev_index)
                            for wl in ("ssv2_64x2048", "darknet53_64x2048", "darknet21_32x1024")]

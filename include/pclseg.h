@@ -9,7 +9,9 @@
  * ctypes binding for that call needs; each cites the reference lines it replaces.
  *
  * Conventions
- *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary: every entry point is a
+ *     function-try-block; std::bad_alloc / std::length_error become PCLSEG_ERR_OOM, anything else
+ *     PCLSEG_ERR_INTERNAL (tests/test_host.py::test_allocation_failure_is_a_status_not_an_abort).
  *   - Every function returns int: 0 = PCLSEG_OK, negative = pclseg_status.  The text of the
  *     last failure is available from pclseg_last_error().
  *   - The caller owns every buffer it passes.  `mem` says where the caller's buffers live:
@@ -47,8 +49,11 @@ typedef enum pclseg_status {
   PCLSEG_ERR_HIP = -4,            /* HIP runtime error (incl. "no GPU")                     */
   PCLSEG_ERR_OOM = -5,
   PCLSEG_ERR_STATE = -6,          /* forward before finalize, set_weight after finalize     */
-  PCLSEG_ERR_RANGE = -7           /* split-f16 mode: an activation reached |v| >= 65504 (f16 range);
+  PCLSEG_ERR_RANGE = -7,          /* split-f16 mode: an activation reached |v| >= 65504 (f16 range);
                                      the outputs of the offending call are not valid            */
+  PCLSEG_ERR_INTERNAL = -8        /* a C++ exception other than an allocation failure was stopped at the
+                                     boundary (allocation failures are PCLSEG_ERR_OOM); message in
+                                     pclseg_last_error.  Nothing ever propagates into the caller.   */
 } pclseg_status;
 
 /* model_map keys of the reference (utils/args_loader.py:36-40); darknet21/53 differ only in
@@ -127,6 +132,11 @@ typedef struct pclseg_plan_info {
 } pclseg_plan_info;
 
 int pclseg_version(void);
+/* First 16 hex digits of the sha256 over the sources this binary was built from (csrc/pclseg_kernels.h,
+ * pclseg_graph.h, pclseg_api.hip, include/pclseg.h, concatenated in that order; "unknown" when built outside
+ * the Makefile).  bench.py compares it with the sources beside it: a profile or traffic figure is only
+ * attributed to a binary whose hash matches. */
+const char* pclseg_build_sha(void);
 
 /* Last error text of `h` (or of the last failed handle-less call when h is NULL).
  * Never returns NULL. */
@@ -179,9 +189,15 @@ int pclseg_set_stream(pclseg_handle* h, void* hip_stream);
 /* Wait for the handle's stream.  Returns PCLSEG_ERR_RANGE if a split-f16 kernel since the last
  * check saw an out-of-range activation: the flag is one sticky word, so EVERY asynchronous call
  * enqueued since the previous check is suspect.  With PCLSEG_FLAG_RANGE_FALLBACK the handle remembers
- * those calls (up to 4096) and re-runs all of them, oldest first, in exact float32 and returns
- * PCLSEG_OK; their buffers must still be valid.  A PCLSEG_MEM_HOST forward that observes a flag raised
- * by earlier asynchronous calls does the same (or says so in its PCLSEG_ERR_RANGE message). */
+ * those calls (up to 256) and re-runs all of them, oldest first, in exact float32 and returns
+ * PCLSEG_OK.  A PCLSEG_MEM_HOST forward that observes a flag raised by earlier asynchronous calls does the
+ * same (or says so in its PCLSEG_ERR_RANGE message).
+ * COMPLETION RULE for PCLSEG_FLAG_RANGE_FALLBACK handles: pclseg_sync (or a PCLSEG_MEM_HOST forward) is the
+ * ONLY point at which an asynchronous call is complete.  The repair re-reads the caller's INPUT pointers and
+ * re-writes its OUTPUT pointers, so until that point every buffer of every un-synced call must stay allocated
+ * and its inputs unmodified — synchronising the HIP stream yourself does NOT release them (without the flag
+ * it does: nothing is replayed).  More than 256 un-synced calls: a range overflow is reported as
+ * PCLSEG_ERR_RANGE instead of repaired. */
 int pclseg_sync(pclseg_handle* h);
 
 /* Page-locked host memory for the PCLSEG_MEM_HOST boundary (the reference hands NumPy arrays to

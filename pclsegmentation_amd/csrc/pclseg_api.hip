@@ -28,6 +28,7 @@ using namespace pclseg;
 namespace {
 
 thread_local std::string g_last_error;
+thread_local const char* g_static_error = nullptr;   // set when not even the message string could be built (exception barrier)
 
 constexpr double kBnEps = 1e-3;  // Keras BatchNormalization default (no epsilon= in nets/*.py)
 
@@ -102,7 +103,7 @@ struct pclseg_handle {
     int32_t* preds = nullptr; float* probs = nullptr; float* logits = nullptr; uint8_t* mask_out = nullptr;
     int mem = PCLSEG_MEM_DEVICE;
   };
-  static constexpr size_t kMaxPending = 4096;
+  static constexpr size_t kMaxPending = 256;
   std::vector<PendingCall> pending;
   bool pending_overflow = false;
   int unchecked_calls = 0;       // asynchronous calls enqueued since the range flag was last read
@@ -112,6 +113,7 @@ struct pclseg_handle {
 namespace {
 
 int fail(pclseg_handle* h, int code, const std::string& msg) {
+  g_static_error = nullptr;
   g_last_error = msg;
   if (h) h->err = msg;
   return code;
@@ -200,6 +202,7 @@ inline void split_store(double w, int k, _Float16* hi_dst, _Float16* lo_dst, Sca
   const float ws = (float)std::ldexp(w, k);
   if (st && !std::isfinite(ws)) st->nonfinite = true;
   const _Float16 hi = (_Float16)ws;
+  if (st && !std::isfinite((float)hi)) st->nonfinite = true;   // |ws| >= 65520 rounds to inf: hi = inf, lo = NaN
   *hi_dst = hi;
   *lo_dst = (_Float16)(ws - (float)hi);
 }
@@ -1270,7 +1273,7 @@ int forward_impl(pclseg_handle* h, const float* input, bool raw, const uint8_t* 
   int rc = sweep(h, input, raw, mask_in, n, preds, probs, logits, mask_out, mem, h->exact || h->force_exact);
   if (rc) { drain_after_error(h); return rc; }
   if (mem != PCLSEG_MEM_HOST) {   // asynchronous: pclseg_sync reports / repairs a range overflow
-    ++h->unchecked_calls;
+    if (h->unchecked_calls < INT32_MAX) ++h->unchecked_calls;   // saturates: handles that never call pclseg_sync
     if (h->fallback && !h->force_exact) {
       if (h->pending.size() < pclseg_handle::kMaxPending) {
         pclseg_handle::PendingCall c;
@@ -1389,6 +1392,45 @@ size_t packed_bytes(const PackedHeader& ph) {
   return sizeof(PackedHeader) + (size_t)ph.n_bias * 4 + (size_t)ph.n_w16 * 2 + (size_t)ph.n_w32 * 4;
 }
 
+
+// ---- exception barrier of the C ABI (include/pclseg.h: "no exceptions cross the boundary") --------
+// Every extern "C" entry point is a function-try-block that ends in PCLSEG_CATCH: whatever the host-side
+// code throws (std::bad_alloc from the BatchNorm folding / fragment packing of 53 M parameters, a
+// std::length_error from a vector sized by a hostile desc, anything else) becomes a status code and a
+// message in pclseg_last_error instead of std::terminate in the caller's process.
+
+int on_exception(const pclseg_handle* ch) noexcept {
+  pclseg_handle* h = const_cast<pclseg_handle*>(ch);
+  int code = PCLSEG_ERR_INTERNAL;
+  const char* what = "unknown C++ exception";
+  char buf[256];
+  try { throw; }
+  catch (const std::bad_alloc&) { code = PCLSEG_ERR_OOM; what = "out of host memory (std::bad_alloc)"; }
+  catch (const std::length_error& e) {
+    code = PCLSEG_ERR_OOM;
+    snprintf(buf, sizeof(buf), "allocation size out of range (std::length_error: %s)", e.what());
+    what = buf;
+  }
+  catch (const std::exception& e) {
+    snprintf(buf, sizeof(buf), "internal error (C++ exception: %s)", e.what());
+    what = buf;
+  }
+  catch (...) {}
+  try {
+    return fail(h, code, what);
+  } catch (...) {
+    g_static_error = code == PCLSEG_ERR_OOM ? "out of host memory (std::bad_alloc)" : "internal error (C++ exception)";
+    return code;
+  }
+}
+#define PCLSEG_CATCH(h) catch (...) { return on_exception(h); }
+
+// pclseg_create: the half-built handle is released on every exit path, also when something throws
+struct HandleGuard {
+  pclseg_handle* h;
+  ~HandleGuard() { if (h) (void)pclseg_destroy(h); }
+};
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -1396,12 +1438,18 @@ extern "C" {
 
 int pclseg_version(void) { return PCLSEG_VERSION; }
 
-const char* pclseg_last_error(const pclseg_handle* h) {
+#ifndef PCLSEG_SRC_SHA
+#define PCLSEG_SRC_SHA "unknown"
+#endif
+const char* pclseg_build_sha(void) { return PCLSEG_SRC_SHA; }
+
+const char* pclseg_last_error(const pclseg_handle* h) try {
+  if (g_static_error) return g_static_error;
   if (h) return h->err.c_str();
   return g_last_error.c_str();
-}
+} catch (...) { return "pclseg_last_error: internal error"; }
 
-int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out) {
+int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out) try {
   if (!out) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "out is NULL");
   Graph g;
   int rc = build_graph(desc, &g);
@@ -1417,9 +1465,9 @@ int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out) {
   const bool exact = (desc->flags & PCLSEG_FLAG_EXACT_F32) != 0;
   out->packed_weight_bytes = (exact ? g.packed32_floats * 4 : g.packed16_halfs * 2) + g.packed_bias_floats * 4;
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
-int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) {
+int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
   if (!buf || !cap) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "buf is NULL");
   Graph g;
   int rc = build_graph(desc, &g);
@@ -1460,25 +1508,20 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) {
   if (out.size() + 1 > cap) return fail(nullptr, PCLSEG_ERR_BAD_ARG, fmt("buffer of %zu bytes, the op list needs %zu", cap, out.size() + 1));
   memcpy(buf, out.c_str(), out.size() + 1);
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
-int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
+int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) try {
   if (!out) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
+  if (!desc) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "desc is NULL");
   pclseg_handle* h = new pclseg_handle();
+  HandleGuard hg{h};            // releases the half-built handle on every early exit, thrown or returned
   int rc = build_graph(desc, &h->g);
-  if (rc) {
-    std::string msg = h->g.error;
-    delete h;
-    return fail(nullptr, rc, msg);
-  }
+  if (rc) return fail(nullptr, rc, h->g.error);
   h->device = desc->device;
   h->host_w.resize(h->g.weights.size());
   h->is_set.assign(h->g.weights.size(), 0);
-  auto bail = [&](int code, const std::string& msg) {
-    pclseg_destroy(h);
-    return fail(nullptr, code, msg);
-  };
+  auto bail = [&](int code, const std::string& msg) { return fail(nullptr, code, msg); };
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -1495,8 +1538,7 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
   const size_t arena_bytes = (size_t)h->g.arena_floats * sizeof(float);
   const size_t mask_bytes = (size_t)h->g.micro_batch * desc->height * desc->width;
   {
-    const char* env = getenv("PCLSEG_LANES");  // tuning override
-    int lanes = env ? atoi(env) : 3;
+    int lanes = debug_env("PCLSEG_LANES", 3);  // tuning override
     if (desc->flags & PCLSEG_FLAG_KEEP_ACTIVATIONS) lanes = 1;  // debug reads need one arena
     h->nlanes = std::max(1, std::min(lanes, (int)pclseg_handle::kMaxLanes));
   }
@@ -1530,11 +1572,12 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) {
   if (e != hipSuccess)
     return bail(e == hipErrorOutOfMemory ? PCLSEG_ERR_OOM : PCLSEG_ERR_HIP,
                 fmt("hipMalloc(parameters): %s", hipGetErrorString(e)));
+  hg.h = nullptr;
   *out = h;
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
-int pclseg_destroy(pclseg_handle* h) {
+int pclseg_destroy(pclseg_handle* h) try {
   if (!h) return PCLSEG_OK;
   DeviceGuard guard(h->device);
   for (int l = 0; l < pclseg_handle::kMaxLanes; ++l) {
@@ -1562,12 +1605,12 @@ int pclseg_destroy(pclseg_handle* h) {
     if (p) (void)hipFree(p);
   delete h;
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
 int pclseg_num_weights(const pclseg_handle* h) { return h ? (int)h->g.weights.size() : PCLSEG_ERR_BAD_ARG; }
 
 int pclseg_weight_info(const pclseg_handle* h, int index, char* name, size_t name_cap,
-                       int64_t shape[4], int* ndim) {
+                       int64_t shape[4], int* ndim) try {
   if (!h || index < 0 || index >= (int)h->g.weights.size())
     return fail(const_cast<pclseg_handle*>(h), PCLSEG_ERR_BAD_ARG, "bad weight index");
   const WeightInfo& w = h->g.weights[index];
@@ -1575,10 +1618,10 @@ int pclseg_weight_info(const pclseg_handle* h, int index, char* name, size_t nam
   if (shape) for (int i = 0; i < 4; ++i) shape[i] = w.shape[i];
   if (ndim) *ndim = w.ndim;
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
 int pclseg_set_weight(pclseg_handle* h, const char* keras_path, const float* data,
-                      const int64_t* shape, int ndim) {
+                      const int64_t* shape, int ndim) try {
   if (!h || !keras_path || !data || !shape) return fail(h, PCLSEG_ERR_BAD_ARG, "NULL argument");
   if (h->finalized) return fail(h, PCLSEG_ERR_STATE, "set_weight after finalize");
   auto it = h->g.weight_index.find(keras_path);
@@ -1597,9 +1640,9 @@ int pclseg_set_weight(pclseg_handle* h, const char* keras_path, const float* dat
   h->host_w[it->second].assign(data, data + w.numel());
   h->is_set[it->second] = 1;
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_finalize(pclseg_handle* h) {
+int pclseg_finalize(pclseg_handle* h) try {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
   if (h->finalized) return fail(h, PCLSEG_ERR_STATE, "finalize called twice");
   for (size_t i = 0; i < h->is_set.size(); ++i)
@@ -1752,15 +1795,15 @@ int pclseg_finalize(pclseg_handle* h) {
   // the Keras-layout copies are no longer needed
   for (auto& v : h->host_w) std::vector<float>().swap(v);
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_packed_size(const pclseg_handle* h, size_t* bytes) {
+int pclseg_packed_size(const pclseg_handle* h, size_t* bytes) try {
   if (!h || !bytes) return fail(const_cast<pclseg_handle*>(h), PCLSEG_ERR_BAD_ARG, "NULL argument");
   *bytes = packed_bytes(packed_header(h));
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_export_packed(pclseg_handle* h, void* dst, size_t capacity, int mem) {
+int pclseg_export_packed(pclseg_handle* h, void* dst, size_t capacity, int mem) try {
   if (!h || !dst) return fail(h, PCLSEG_ERR_BAD_ARG, "NULL argument");
   if (!h->finalized) return fail(h, PCLSEG_ERR_STATE, "export_packed before pclseg_finalize");
   if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE) return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
@@ -1779,9 +1822,9 @@ int pclseg_export_packed(pclseg_handle* h, void* dst, size_t capacity, int mem) 
   p += (size_t)ph.n_w16 * 2;
   if (ph.n_w32) HIP_TRY(h, hipMemcpy(p, h->d_w32, (size_t)ph.n_w32 * 4, body));
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_import_packed(pclseg_handle* h, const void* src, size_t bytes, int mem) {
+int pclseg_import_packed(pclseg_handle* h, const void* src, size_t bytes, int mem) try {
   if (!h || !src) return fail(h, PCLSEG_ERR_BAD_ARG, "NULL argument");
   if (h->finalized) return fail(h, PCLSEG_ERR_STATE, "import_packed on a finalized handle");
   if (mem != PCLSEG_MEM_HOST && mem != PCLSEG_MEM_DEVICE) return fail(h, PCLSEG_ERR_BAD_ARG, fmt("unknown mem %d", mem));
@@ -1796,11 +1839,13 @@ int pclseg_import_packed(pclseg_handle* h, const void* src, size_t bytes, int me
     return fail(h, PCLSEG_ERR_BAD_SHAPE,
                 fmt("packed blob does not fit this handle: blob arch %d %dx%d NC %d stride %d math %u version %u "
                     "(%lld bias, %lld f16, %lld f32 scalars, plan %016llx); handle arch %d %dx%d NC %d stride %d math %u version %u "
-                    "(%lld, %lld, %lld, plan %016llx)",
+                    "(%lld, %lld, %lld, plan %016llx); debug switches resolved in THIS process: %s "
+                    "(the exporting process must run the same build with the same PCLSEG_FUSE_* environment)",
                     got.arch, got.height, got.width, got.num_class, got.output_stride, got.math, got.version,
                     (long long)got.n_bias, (long long)got.n_w16, (long long)got.n_w32, (unsigned long long)got.plan_hash,
                     want.arch, want.height, want.width, want.num_class, want.output_stride, want.math, want.version,
-                    (long long)want.n_bias, (long long)want.n_w16, (long long)want.n_w32, (unsigned long long)want.plan_hash));
+                    (long long)want.n_bias, (long long)want.n_w16, (long long)want.n_w32, (unsigned long long)want.plan_hash,
+                    DebugSwitches::text().c_str()));
   if (bytes < packed_bytes(got)) return fail(h, PCLSEG_ERR_BAD_ARG, "blob truncated");
   const hipMemcpyKind body = mem == PCLSEG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   const char* p = (const char*)src + sizeof(got);
@@ -1813,15 +1858,15 @@ int pclseg_import_packed(pclseg_handle* h, const void* src, size_t bytes, int me
   h->finalized = true;
   for (auto& v : h->host_w) std::vector<float>().swap(v);
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_set_stream(pclseg_handle* h, void* hip_stream) {
+int pclseg_set_stream(pclseg_handle* h, void* hip_stream) try {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
   h->stream = (hipStream_t)hip_stream;
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_sync(pclseg_handle* h) {
+int pclseg_sync(pclseg_handle* h) try {
   if (!h) return fail(nullptr, PCLSEG_ERR_BAD_ARG, "handle is NULL");
   DeviceGuard guard(h->device);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1832,9 +1877,9 @@ int pclseg_sync(pclseg_handle* h) {
   if (!fired) { clear_pending(h); return PCLSEG_OK; }
   if (!h->fallback) { clear_pending(h); return fail(h, PCLSEG_ERR_RANGE, kRangeMsg); }
   return repair_pending(h);
-}
+} PCLSEG_CATCH(h)
 
-void* pclseg_host_alloc(size_t bytes) {
+void* pclseg_host_alloc(size_t bytes) try {
   void* p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
@@ -1842,36 +1887,36 @@ void* pclseg_host_alloc(size_t bytes) {
     return nullptr;
   }
   return p;
-}
+} catch (...) { (void)on_exception(nullptr); return nullptr; }
 
-int pclseg_host_free(void* p) {
+int pclseg_host_free(void* p) try {
   if (!p) return PCLSEG_OK;
   HIP_TRY(nullptr, hipHostFree(p));
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_forward(pclseg_handle* h, const float* lidar, const uint8_t* mask, int n, int32_t* preds,
-                   float* probs, float* logits, int mem) {
+                   float* probs, float* logits, int mem) try {
   return forward_impl(h, lidar, false, mask, n, preds, probs, logits, nullptr, mem);
-}
+} PCLSEG_CATCH(h)
 
 int pclseg_forward_raw(pclseg_handle* h, const float* scans, int n, int32_t* preds, float* probs,
-                       float* logits, uint8_t* mask_out, int mem) {
+                       float* logits, uint8_t* mask_out, int mem) try {
   return forward_impl(h, scans, true, nullptr, n, preds, probs, logits, mask_out, mem);
-}
+} PCLSEG_CATCH(h)
 
 int pclseg_num_tensors(const pclseg_handle* h) { return h ? (int)h->g.tensors.size() : PCLSEG_ERR_BAD_ARG; }
 
-int pclseg_tensor_info(const pclseg_handle* h, int index, char* name, size_t name_cap, int64_t shape[4]) {
+int pclseg_tensor_info(const pclseg_handle* h, int index, char* name, size_t name_cap, int64_t shape[4]) try {
   if (!h || index < 0 || index >= (int)h->g.tensors.size())
     return fail(const_cast<pclseg_handle*>(h), PCLSEG_ERR_BAD_ARG, "bad tensor index");
   const TensorInfo& t = h->g.tensors[index];
   if (name && name_cap) snprintf(name, name_cap, "%s", t.name.c_str());
   if (shape) { shape[0] = h->last_count; shape[1] = t.H; shape[2] = t.W; shape[3] = t.C; }
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
-int pclseg_read_tensor(pclseg_handle* h, int index, float* host_out, size_t capacity_floats) {
+int pclseg_read_tensor(pclseg_handle* h, int index, float* host_out, size_t capacity_floats) try {
   if (!h || !host_out || index < 0 || index >= (int)h->g.tensors.size())
     return fail(h, PCLSEG_ERR_BAD_ARG, "bad argument to read_tensor");
   const TensorInfo& t = h->g.tensors[index];
@@ -1890,11 +1935,11 @@ int pclseg_read_tensor(pclseg_handle* h, int index, float* host_out, size_t capa
     }
   }
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(h)
 
 // ---- single-operator entry points
 int pclseg_op_normalize(const float* scans, int n, int h, int w, const double mean[5],
-                        const double std[5], float* lidar6, uint8_t* mask) {
+                        const double std[5], float* lidar6, uint8_t* mask) try {
   if (!scans || !lidar6 || !mean || !std || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_normalize");
   NormArgs na;
@@ -1905,12 +1950,12 @@ int pclseg_op_normalize(const float* scans, int n, int h, int w, const double me
   HIP_TRY(nullptr, hipGetLastError());
   HIP_TRY(nullptr, hipDeviceSynchronize());
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_conv2d(const float* x, int n, int h, int w, int cin, const float* kernel, int kh, int kw,
                      int cout, int stride_w, const float* bias, const float* bn_gamma,
                      const float* bn_beta, const float* bn_mean, const float* bn_var, int act,
-                     const float* residual, float* y, int math) {
+                     const float* residual, float* y, int math) try {
   if (!x || !kernel || !y || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_conv2d");
   if (cin % 4 || cout % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "Cin and Cout must be multiples of 4");
@@ -1931,12 +1976,12 @@ int pclseg_op_conv2d(const float* x, int n, int h, int w, int cin, const float* 
   a.in = x; a.out = y; a.out_C = cout;
   if (residual) { a.res1 = residual; a.res1_C = cout; }
   return run_single_op(&op, &f, n, h, w, a, math);
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_conv2d_transpose(const float* x, int n, int h, int w, int cin, const float* kernel,
                                int cout, const float* bias, const float* bn_gamma,
                                const float* bn_beta, const float* bn_mean, const float* bn_var,
-                               int act, float* y, int math) {
+                               int act, float* y, int math) try {
   if (!x || !kernel || !y || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_conv2d_transpose");
   if (cin % 4 || cout % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "Cin and Cout must be multiples of 4");
@@ -1963,9 +2008,9 @@ int pclseg_op_conv2d_transpose(const float* x, int n, int h, int w, int cin, con
   memset(&a, 0, sizeof(a));
   a.in = x; a.out = y; a.out_C = cout;
   return run_single_op(&op, f, n, h, w, a, math);
-}
+} PCLSEG_CATCH(nullptr)
 
-int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int stride_w, float* y) {
+int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int stride_w, float* y) try {
   if (!x || !y || n <= 0 || h <= 0 || w <= 0 || k <= 0 || (stride_w != 1 && stride_w != 2))
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_max_pool");
   if (c % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "C must be a multiple of 4");
@@ -1981,11 +2026,11 @@ int pclseg_op_max_pool(const float* x, int n, int h, int w, int c, int k, int st
   HIP_TRY(nullptr, launch_pool(x, y, n, h, w, c, k, k, stride_w, nullptr));
   HIP_TRY(nullptr, hipDeviceSynchronize());
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int cin,
                    const float* kernel, const float* bias, int num_class, int none_index,
-                   int32_t* preds, float* probs, float* logits, int math) {
+                   int32_t* preds, float* probs, float* logits, int math) try {
   if (!x || !mask || !kernel || !bias || !preds || n <= 0 || h <= 0 || w <= 0)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_head");
   if (cin % 4 || num_class < 2 || num_class > 64)
@@ -2003,10 +2048,10 @@ int pclseg_op_head(const float* x, const uint8_t* mask, int n, int h, int w, int
   a.in = x;
   a.mask = mask; a.preds = preds; a.probs = probs; a.logits = logits; a.none_index = none_index;
   return run_single_op(&op, &f, n, h, w, a, math);
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_split_f16_roundtrip(const float* kernel, int kh, int kw, int cin, int cout, double* recon,
-                                  int32_t* exponents) {
+                                  int32_t* exponents) try {
   if (!kernel || !recon || cin <= 0 || cout <= 0 || !((kh == 1 && kw == 1) || (kh == 3 && kw == 3)))
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_split_f16_roundtrip");
   if (cin % 4 || cout % 4) return fail(nullptr, PCLSEG_ERR_BAD_SHAPE, "Cin and Cout must be multiples of 4");
@@ -2050,10 +2095,10 @@ int pclseg_op_split_f16_roundtrip(const float* kernel, int kh, int kw, int cin, 
   if (exponents)
     for (int co = 0; co < cout; ++co) exponents[co] = -std::ilogb(inv[co]);
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size_t count,
-                               int num_class, int64_t* cm, void* hip_stream) {
+                               int num_class, int64_t* cm, void* hip_stream) try {
   if (!labels || !preds || !cm || num_class < 1 || num_class > 64)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_confusion_matrix");
   if (count == 0) return PCLSEG_OK;
@@ -2063,12 +2108,12 @@ int pclseg_op_confusion_matrix(const int32_t* labels, const int32_t* preds, size
                      reinterpret_cast<unsigned long long*>(cm));
   HIP_TRY(nullptr, hipGetLastError());
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_project_ex(const pclseg_proj_desc* d, const float* points, int point_stride, size_t m,
                          const int32_t* ring, const float* depth, const int32_t* labels,
                          const int32_t* label_lut, int lut_size, float* image, int32_t* proj_idx,
-                         uint64_t* scratch, void* hip_stream) {
+                         uint64_t* scratch, void* hip_stream) try {
   if (!d || !points || !image || !scratch || d->h <= 0 || d->w <= 0 || m > 0x7ffffffeull || point_stride < 4)
     return fail(nullptr, PCLSEG_ERR_BAD_ARG, "bad argument to op_project_ex");
   if (d->row_mode < 0 || d->row_mode > 1 || d->col_mode < 0 || d->col_mode > 1 || d->winner < 0 || d->winner > 1 ||
@@ -2106,11 +2151,11 @@ int pclseg_op_project_ex(const pclseg_proj_desc* d, const float* points, int poi
                      npix, image, proj_idx, pa);
   HIP_TRY(nullptr, hipGetLastError());
   return PCLSEG_OK;
-}
+} PCLSEG_CATCH(nullptr)
 
 int pclseg_op_project(const float* points, size_t m, int h, int w, float fov_up, float fov_down,
                       float empty, float* image5, int32_t* proj_idx, uint64_t* scratch,
-                      void* hip_stream) {
+                      void* hip_stream) try {
   pclseg_proj_desc d;
   memset(&d, 0, sizeof(d));
   d.h = h; d.w = w;
@@ -2119,6 +2164,6 @@ int pclseg_op_project(const float* points, size_t m, int h, int w, float fov_up,
   d.fov_up = fov_up; d.fov_down = fov_down; d.empty = empty;
   return pclseg_op_project_ex(&d, points, 4, m, nullptr, nullptr, nullptr, nullptr, 0, image5, proj_idx,
                               scratch, hip_stream);
-}
+} PCLSEG_CATCH(nullptr)
 
 }  // extern "C"

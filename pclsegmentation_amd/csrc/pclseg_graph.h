@@ -32,6 +32,25 @@ inline int tune_env(const char* name, int dflt) { const char* v = getenv(name); 
 constexpr int tune_env(const char*, int dflt) { return dflt; }
 #endif
 
+// The debug switches the SHIPPED library honours (PCLSEG_LANES and the PCLSEG_FUSE_* set).  They are
+// read in ONE place, which also remembers what each resolved to: a stray variable in a rank's environment changes
+// that rank's plan, and the error that reports it (pclseg_import_packed's plan mismatch) prints the resolved set.
+struct DebugSwitches {
+  static std::vector<std::pair<std::string, int>>& seen() { static std::vector<std::pair<std::string, int>> v; return v; }
+  static std::string text() {
+    std::string t;
+    for (const auto& kv : seen()) t += (t.empty() ? "" : " ") + kv.first + "=" + std::to_string(kv.second);
+    return t.empty() ? "none read yet" : t;
+  }
+};
+inline int debug_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  const int r = v ? atoi(v) : dflt;
+  for (auto& kv : DebugSwitches::seen()) if (kv.first == name) { kv.second = r; return r; }
+  DebugSwitches::seen().emplace_back(name, r);
+  return r;
+}
+
 enum OpKind { OP_CONV = 0, OP_POOL = 2, OP_HEAD = 3, OP_CAM = 4 };
 
 struct WeightInfo {
@@ -526,16 +545,16 @@ inline void build_squeezesegv2(Graph* g) {
   // N = 4, 6, 7, 8, 9 (:302-312) and N = 10, 11, 12 (:313-318): there the
   // squeeze is computed by fireN's expand blocks and the expand output is never written (split-f16
   // arithmetic only; every intermediate stays observable with KEEP_ACTIVATIONS, which disables it)
-  static const int fuse_env = getenv("PCLSEG_FUSE_SQ") ? atoi(getenv("PCLSEG_FUSE_SQ")) : 1;
-  static const int fuse_pool = getenv("PCLSEG_FUSE_POOL") ? atoi(getenv("PCLSEG_FUSE_POOL")) : 1;   // pool -> squeeze in one kernel
-  static const int fuse_cam = getenv("PCLSEG_FUSE_CAM") ? atoi(getenv("PCLSEG_FUSE_CAM")) : 1;   // cam2 -> fire3/squeeze in one kernel
-  static const int fuse_keep = getenv("PCLSEG_FUSE_KEEP") ? atoi(getenv("PCLSEG_FUSE_KEEP")) : 0;   // debug
+  static const int fuse_env = debug_env("PCLSEG_FUSE_SQ", 1);
+  static const int fuse_pool = debug_env("PCLSEG_FUSE_POOL", 1);   // pool -> squeeze in one kernel
+  static const int fuse_cam = debug_env("PCLSEG_FUSE_CAM", 1);   // cam2 -> fire3/squeeze in one kernel
+  static const int fuse_keep = debug_env("PCLSEG_FUSE_KEEP", 0);   // debug
   const bool fuse = fuse_env && !(g->desc.flags & (PCLSEG_FLAG_EXACT_F32 | PCLSEG_FLAG_RANGE_FALLBACK)) &&
                     (fuse_keep || !(g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS));
   auto fire = [&](const std::string& p, int x, int sq_c, int e1, int e3, bool up, int skip,
                   int64_t skip_floats = 0, bool fuse_prev = false) {
     int s;
-    static const int fuse_mask = getenv("PCLSEG_FUSE_MASK") ? atoi(getenv("PCLSEG_FUSE_MASK")) : 255;   // debug: bit per fusion
+    static const int fuse_mask = debug_env("PCLSEG_FUSE_MASK", 255);   // debug: bit per fusion
     const int fuse_bit = p == "fire5" ? 1 : p == "fire7" ? 2 : p == "fire8" ? 4 : p == "fire9" ? 8 : p == "fire10" ? 16 :
                          p == "fire11" ? 32 : p == "fire12" ? 64 : 128;
     if (fuse_prev && fuse && (fuse_mask & fuse_bit) && last_expand >= 0 && g->ops[last_expand].out == x) {
@@ -785,8 +804,8 @@ inline void recompute_lifetimes(Graph* g) {
 // fused next squeeze, fire13 with its fused skip branch) and both tensors are split-f16, the transposed
 // conv moves into the pair's staging (conv_kernel UP) and its launch and its output tensor disappear.
 inline void fuse_upconvs(Graph* g) {
-  static const int on = getenv("PCLSEG_FUSE_UP") ? atoi(getenv("PCLSEG_FUSE_UP")) : 1;
-  static const int fuse_keep = getenv("PCLSEG_FUSE_KEEP") ? atoi(getenv("PCLSEG_FUSE_KEEP")) : 0;   // debug (tests/fused_worker.py)
+  static const int on = debug_env("PCLSEG_FUSE_UP", 1);
+  static const int fuse_keep = debug_env("PCLSEG_FUSE_KEEP", 0);   // debug (tests/fused_worker.py)
   if (!on || (g->desc.flags & (PCLSEG_FLAG_EXACT_F32 | PCLSEG_FLAG_RANGE_FALLBACK))) return;
   if ((g->desc.flags & PCLSEG_FLAG_KEEP_ACTIVATIONS) && !fuse_keep) return;
   std::vector<int> readers(g->tensors.size(), 0);
@@ -820,7 +839,7 @@ inline void fuse_upconvs(Graph* g) {
 // run as ONE kernel that keeps fire13's 64-channel output in LDS (fire_head_kernel): 16 + 32 + 32 -> 64
 // channels, up to 32 classes.
 inline void fuse_head(Graph* g) {
-  static const int on = getenv("PCLSEG_FUSE_HEAD") ? atoi(getenv("PCLSEG_FUSE_HEAD")) : 1;
+  static const int on = debug_env("PCLSEG_FUSE_HEAD", 1);
   const size_t n = g->ops.size();
   if (!on || n < 2) return;
   Op& e = g->ops[n - 2];

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCLSEG_LIB") or os.path.join(_HERE, "libpclseg.so")   # override: A/B of two builds
 
 OK = 0
-ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE, ERR_RANGE = -1, -2, -3, -4, -5, -6, -7
+ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE, ERR_RANGE, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
 MEM_HOST, MEM_DEVICE, MEM_HOST_ASYNC = 0, 1, 2
 FLAG_KEEP_ACTIVATIONS = 1
 FLAG_EXACT_F32 = 2
@@ -29,7 +29,7 @@ ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
 
 # every symbol include/pclseg.h declares (checked by tests/test_host.py::test_library_exports_every_declared_symbol)
 EXPORTS = [
-  "pclseg_version", "pclseg_last_error", "pclseg_plan", "pclseg_plan_ops", "pclseg_create", "pclseg_destroy",
+  "pclseg_version", "pclseg_build_sha", "pclseg_last_error", "pclseg_plan", "pclseg_plan_ops", "pclseg_create", "pclseg_destroy",
   "pclseg_num_weights", "pclseg_weight_info", "pclseg_set_weight", "pclseg_finalize",
   "pclseg_packed_size", "pclseg_export_packed", "pclseg_import_packed",
   "pclseg_set_stream", "pclseg_sync", "pclseg_host_alloc", "pclseg_host_free", "pclseg_forward", "pclseg_forward_raw",
@@ -80,8 +80,18 @@ def load_library():
       "libpclseg.so not found at %s — build it with `make` (or __graft_entry__.build()); "
       "this engine has no CPU fallback" % LIB_PATH)
   lib = ctypes.CDLL(LIB_PATH)
+  if "PCLSEG_LIB" in os.environ:   # A/B against an older build: entry points it lacks fail at the call, not at load
+    class _Missing:
+      def __init__(self, name):
+        self.name, self.argtypes, self.restype = name, None, None
+      def __call__(self, *a):
+        raise RuntimeError("%s is not exported by %s" % (self.name, LIB_PATH))
+    for name in EXPORTS:
+      if not hasattr(lib, name):
+        setattr(lib, name, _Missing(name))
   vp, i32, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
   lib.pclseg_version.restype = ctypes.c_int
+  lib.pclseg_build_sha.argtypes = []
   lib.pclseg_last_error.restype = ctypes.c_char_p
   lib.pclseg_last_error.argtypes = [vp]
   lib.pclseg_plan.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(PlanInfo)]
@@ -93,15 +103,6 @@ def load_library():
                                      ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
   lib.pclseg_set_weight.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(ctypes.c_int64), i32]
   lib.pclseg_finalize.argtypes = [vp]
-  if "PCLSEG_LIB" in os.environ:   # A/B against an older build: entry points it lacks fail at the call, not at load
-    class _Missing:
-      def __init__(self, name):
-        self.name, self.argtypes, self.restype = name, None, None
-      def __call__(self, *a):
-        raise RuntimeError("%s is not exported by %s" % (self.name, LIB_PATH))
-    for name in EXPORTS:
-      if not hasattr(lib, name):
-        setattr(lib, name, _Missing(name))
   lib.pclseg_packed_size.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
   lib.pclseg_export_packed.argtypes = [vp, vp, ctypes.c_size_t, i32]
   lib.pclseg_import_packed.argtypes = [vp, vp, ctypes.c_size_t, i32]
@@ -131,11 +132,17 @@ def load_library():
   lib.pclseg_op_split_f16_roundtrip.argtypes = [f32p, i32, i32, i32, i32, vp, vp]
   for name in EXPORTS:
     fn = getattr(lib, name)
-    if name not in ("pclseg_last_error", "pclseg_host_alloc"):
+    if name not in ("pclseg_last_error", "pclseg_host_alloc", "pclseg_build_sha"):
       fn.restype = ctypes.c_int
   lib.pclseg_host_alloc.restype = ctypes.c_void_p
+  lib.pclseg_build_sha.restype = ctypes.c_char_p
   _lib = lib
   return lib
+
+
+def build_sha():
+  """Source hash baked into the loaded binary (Makefile -DPCLSEG_SRC_SHA), "unknown" for a foreign build."""
+  return load_library().pclseg_build_sha().decode()
 
 
 def _raise(rc, handle=None):

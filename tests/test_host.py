@@ -255,3 +255,59 @@ def test_plan_ops_lists_every_launch_with_its_macs(arch, cfg, h, w):
     assert len(names) == 19                      # + the pre-processing launch = 20 per micro-batch
   else:
     assert names[-1] == "head+head" and "enc5/residual_0/conv2" in names
+
+
+_OOM_CHILD = r"""
+import ctypes, os, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from pclsegmentation_amd import engine as E
+lib = E.load_library()
+vm = [int(l.split()[1]) for l in open("/proc/self/status") if l.startswith("VmSize")][0] * 1024
+resource.setrlimit(resource.RLIMIT_AS, (vm + (512 << 20), vm + (512 << 20)))   # 512 MB of head room
+kernel = np.zeros(16, np.float32)          # never read: the first allocation (2 x 2 GB of fold scales) fails
+recon = np.zeros(16, np.float64)
+rc = lib.pclseg_op_split_f16_roundtrip(E._ptr(kernel), 1, 1, 4, 1 << 28, E._ptr(recon), None)
+msg = lib.pclseg_last_error(None).decode()
+print("RC", rc, "|", msg)
+# the process is alive and the library still works
+rec, exps = E.op_split_f16_roundtrip(np.ones((1, 1, 4, 4), np.float32))
+print("ALIVE", float(rec.sum()))
+"""
+
+
+def test_allocation_failure_is_a_status_not_an_abort():
+  """include/pclseg.h: "no exceptions cross the boundary".  A std::bad_alloc inside the library (forced here
+  with RLIMIT_AS and a fold of 2^28 output channels, in a child process) comes back as PCLSEG_ERR_OOM with a
+  message; the process is not terminated and the next call works."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, "-c", _OOM_CHILD % root], capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+  line = [l for l in r.stdout.splitlines() if l.startswith("RC")][0]
+  assert line.split()[1] == str(E.ERR_OOM) and "bad_alloc" in line, line
+  assert "ALIVE 16.0" in r.stdout
+  with pytest.raises(MemoryError):
+    E.check(E.ERR_OOM)
+
+
+def test_every_entry_point_is_behind_the_exception_barrier():
+  """Source-level: each extern "C" definition with a body of more than one line is a function-try-block."""
+  src = open(os.path.join(os.path.dirname(E.__file__), "csrc", "pclseg_api.hip")).read()
+  body = src[src.index('extern "C" {'):src.index('}  // extern "C"')]
+  defs = re.findall(r"^(?:int|void\*|const char\*) (pclseg_\w+)\([^;{]*\)( try)? \{$", body, re.M)
+  assert len(defs) >= 28 and all(t for _, t in defs), [n for n, t in defs if not t]
+  assert body.count("PCLSEG_CATCH(") + body.count("catch (...)") >= len(defs)
+
+
+def test_binary_carries_the_hash_of_the_sources_it_was_built_from():
+  """Makefile bakes sha256(csrc/* + include/pclseg.h)[:16] into the library; bench.py's csrc_sha() reads the
+  same files in the same order.  (After editing a source without rebuilding this fails: rebuild.)"""
+  import importlib.util
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  assert re.fullmatch(r"[0-9a-f]{16}", E.build_sha()), E.build_sha()
+  assert E.build_sha() == bench.csrc_sha()
