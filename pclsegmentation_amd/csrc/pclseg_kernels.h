@@ -1279,34 +1279,48 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   // output column w = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1); U column pc
   // is image column w0 - 2 + pc (w0 - 2 is even, so pc has the parity of w)
   {
-    constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16;
+    constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16, NU = (UNITS + 1) / 2, NB = 2;
+    static_assert(NU % NB == 0, "units per wave in batches of NB");
+    // (the wave's NU units in batches of NB: the batch's fragment reads, then its NB independent 3-MFMA chains,
+    // then the epilogues — as a rolled loop every unit was a serial chain read -> 3 dependent MFMAs -> split ->
+    // write; all NU at once needs 48 registers this phase does not have: 32 B of scratch)
 #pragma nounroll
-    for (int u0 = 0; u0 < UNITS; u0 += 2) {
-      const int u = u0 + (wave >> 1);
-      const int l = u * 16 + p;
-      const int lc = l < PER ? l : PER - 1;
-      const int pr = lc / (kFhUW / 2), k2 = lc - pr * (kFhUW / 2);
-      const int pc = 2 * k2 + parity;
-      const int h = h0 - 2 + pr, w = w0 - 2 + pc;
-      const bool pv = h >= 0 && h < a.H && w >= 0 && w < a.W;
-      const int tap = g >> 1, c8 = g & 1;
-      const _Float16* sp = S + (pr * kFhSW + k2 + parity + tap) * kFhCSU + c8 * 8;
-      const f16x8 xh = *reinterpret_cast<const f16x8*>(sp);
-      const f16x8 xl = *reinterpret_cast<const f16x8*>(sp + 16);
-      f32x4 au = (f32x4){0.f, 0.f, 0.f, 0.f};
-      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwl, xh, au, 0, 0, 0);
-      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xl, au, 0, 0, 0);
-      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xh, au, 0, 0, 0);
-      {   // (lanes past the last pixel were clamped onto it: they compute and store ITS value again — no branch)
-        f32x4 v = fma4(au, ui, ub);
+    for (int k0 = 0; k0 < NU; k0 += NB) {
+      f16x8 xh[NB], xl[NB];
+      int dst[NB];
+      bool pvv[NB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
+      for (int k = 0; k < NB; ++k) {
+        const int u = 2 * (k0 + k) + (wave >> 1);
+        const int l = u * 16 + p;
+        const int lc = l < PER ? l : PER - 1;
+        const int pr = lc / (kFhUW / 2), k2 = lc - pr * (kFhUW / 2);
+        const int pc = 2 * k2 + parity;
+        const int h = h0 - 2 + pr, w = w0 - 2 + pc;
+        pvv[k] = h >= 0 && h < a.H && w >= 0 && w < a.W;
+        const int tap = g >> 1, c8 = g & 1;
+        const _Float16* sp = S + (pr * kFhSW + k2 + parity + tap) * kFhCSU + c8 * 8;
+        xh[k] = *reinterpret_cast<const f16x8*>(sp);
+        xl[k] = *reinterpret_cast<const f16x8*>(sp + 16);
+        dst[k] = (pr * kFhUW + pc) * kFhCSU + g * 4;
+      }
+      f32x4 au[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) au[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwl, xh[k], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) au[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xl[k], au[k], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) au[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xh[k], au[k], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {   // (lanes past the last pixel were clamped onto it: they compute and store ITS value again — no branch)
+        f32x4 v = fma4(au[k], ui, ub);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pvv[k] ? fmaxf(v[e], 0.0f) : 0.0f;
         vmax = absmax4(vmax, v);
         f16x4 hi, lo;
         split4(v, hi, lo);
-        _Float16* d = U + (pr * kFhUW + pc) * kFhCSU + g * 4;
-        *reinterpret_cast<f16x4*>(d) = hi;
-        *reinterpret_cast<f16x4*>(d + 16) = lo;
+        *reinterpret_cast<f16x4*>(U + dst[k]) = hi;
+        *reinterpret_cast<f16x4*>(U + dst[k] + 16) = lo;
       }
     }
   }
@@ -1458,25 +1472,46 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
 #pragma unroll
       for (int t = 0; t < NCT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fbase = p * kFhCSF + g * 8;
+    // Software-pipelined over the (K-step, row) groups: the two fragment reads of group k + 1 are issued BEFORE the
+    // six MFMAs of group k and land while those run (hipcc, left alone, emitted `2 reads, wait, 6 MFMAs` per
+    // group: ~100 cycles of LDS latency in front of every 96 cycles of matrix work, 36 times per wave).  A
+    // scheduling barrier per group keeps that order; steps 0-3 exist for every wave (32 groups), step 4 for waves
+    // 0 and 1 only (wave-uniform branch, its own prologue).
+    auto frag_off = [&](const int st, const int r) {
+      const int tap = st >> 1, ti = (tap * 11) >> 5, tj = tap - 3 * ti;
+      return fbase + (ti * kFhFW + tj) * kFhCSF + (st & 1) * 32 + r * (kFhFW * kFhCSF);
+    };
+    auto sweep = [&](const int i0, const int i1) {
+      f16x8 xh = *reinterpret_cast<const f16x8*>(F + frag_off(wave + 4 * i0, 0));
+      f16x8 xl = *reinterpret_cast<const f16x8*>(F + frag_off(wave + 4 * i0, 0) + 64);
 #pragma unroll
-    for (int i = 0; i < kHdSteps; ++i) {
-      const int st = wave + 4 * i;
-      if (st < 18) {   // wave-uniform
-        const int tap = st >> 1, ti = (tap * 11) >> 5, tj = tap - 3 * ti;
-        const int koff = fbase + (ti * kFhFW + tj) * kFhCSF + (st & 1) * 32;
+      for (int i = i0; i < i1; ++i) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const f16x8 xh = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF));
-          const f16x8 xl = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF) + 64);
+          f16x8 nh = xh, nl = xl;
+          const bool more = r < 7 || i + 1 < i1;
+          if (more) {
+            const int off = r < 7 ? frag_off(wave + 4 * i, r + 1) : frag_off(wave + 4 * (i + 1), 0);
+            nh = *reinterpret_cast<const f16x8*>(F + off);
+            nl = *reinterpret_cast<const f16x8*>(F + off + 64);
+          }
 #pragma unroll
           for (int t = 0; t < NCT; ++t) {
             acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl[i][t], xh, acc[r][t], 0, 0, 0);
             acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xl, acc[r][t], 0, 0, 0);
             acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xh, acc[r][t], 0, 0, 0);
           }
+          // (order inside the group: the two DS reads FIRST, then the MFMAs — left to itself the scheduler sinks
+          // the reads to two MFMAs before their use to save registers)
+          if (more) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * NCT, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          xh = nh; xl = nl;
         }
       }
-    }
+    };
+    sweep(0, 4);
+    if (wave + 16 < 18) sweep(4, 5);   // wave-uniform
     stamp(6);
     // partial sums -> LDS [wave][row][tile][lane] (F and U are dead once every wave is here)
     f32x4* part = reinterpret_cast<f32x4*>(smem_raw);

@@ -128,3 +128,17 @@ def test_oracle_matches_tensorflow(path):
   decided = g["margin"] > 2e-3
   assert np.array_equal(tfv["predictions"][decided], g["preds"][decided])
   assert np.allclose(tfv["probabilities"].sum(-1), 1.0, atol=1e-5)
+
+
+def test_tf_golden_generator_dry_run():
+  """tests/golden/make_tf_golden.py cannot run here (no TensorFlow); its --check mode builds the same Keras-layer
+  tree on a shape-only stand-in and validates it against nets/spec.py: every weight path resolves attribute by
+  attribute to a leaf of the right kind / filters / kernel / stride / use_bias, the forward walk calls each leaf
+  once with the spec's input channels, adds join equal shapes, logits are [N, H, W, NUM_CLASS]."""
+  import subprocess
+  import sys
+  here = _os.path.dirname(_os.path.abspath(__file__))
+  r = subprocess.run([sys.executable, _os.path.join(here, "golden", "make_tf_golden.py"), "--check"],
+                     capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+  assert r.stdout.count("check ok:") == 6
