@@ -24,7 +24,12 @@ stamps: $(SRCS)
 tuning: $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -DPCLSEG_TUNING -o pclsegmentation_amd/libpclseg_tuning.so $(CSRC)/pclseg_api.hip
 
-clean:
-	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so pclsegmentation_amd/libpclseg_tuning.so
+# experiment build of the round: kernel variants that have NOT yet been verified on an MI355X are compiled only
+# with -DPCLSEG_R4X (A/B: PCLSEG_LIB=.../libpclseg_r4x.so); the shipped library carries the verified code paths
+r4x: $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -DPCLSEG_R4X -o pclsegmentation_amd/libpclseg_r4x.so $(CSRC)/pclseg_api.hip
 
-.PHONY: all clean stamps tuning
+clean:
+	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so pclsegmentation_amd/libpclseg_tuning.so pclsegmentation_amd/libpclseg_r4x.so pclsegmentation_amd/libpclseg_base.so
+
+.PHONY: all clean stamps tuning r4x

@@ -1279,6 +1279,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   // output column w = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1); U column pc
   // is image column w0 - 2 + pc (w0 - 2 is even, so pc has the parity of w)
   {
+#ifdef PCLSEG_R4X
     constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16, NU = (UNITS + 1) / 2, NB = 2;
     static_assert(NU % NB == 0, "units per wave in batches of NB");
     // (the wave's NU units in batches of NB: the batch's fragment reads, then its NB independent 3-MFMA chains,
@@ -1324,6 +1325,39 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
       }
     }
   }
+#else
+    constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16;
+#pragma nounroll
+    for (int u0 = 0; u0 < UNITS; u0 += 2) {
+      const int u = u0 + (wave >> 1);
+      const int l = u * 16 + p;
+      const int lc = l < PER ? l : PER - 1;
+      const int pr = lc / (kFhUW / 2), k2 = lc - pr * (kFhUW / 2);
+      const int pc = 2 * k2 + parity;
+      const int h = h0 - 2 + pr, w = w0 - 2 + pc;
+      const bool pv = h >= 0 && h < a.H && w >= 0 && w < a.W;
+      const int tap = g >> 1, c8 = g & 1;
+      const _Float16* sp = S + (pr * kFhSW + k2 + parity + tap) * kFhCSU + c8 * 8;
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(sp);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(sp + 16);
+      f32x4 au = (f32x4){0.f, 0.f, 0.f, 0.f};
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwl, xh, au, 0, 0, 0);
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xl, au, 0, 0, 0);
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xh, au, 0, 0, 0);
+      {   // (lanes past the last pixel were clamped onto it: they compute and store ITS value again — no branch)
+        f32x4 v = fma4(au, ui, ub);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
+        vmax = absmax4(vmax, v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        _Float16* d = U + (pr * kFhUW + pc) * kFhCSU + g * 4;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 16) = lo;
+      }
+    }
+  }
+#endif
   lds_barrier();   // U complete (and every wave is done reading S: F may be overwritten)
   stamp(2);
 
@@ -1472,6 +1506,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
 #pragma unroll
       for (int t = 0; t < NCT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fbase = p * kFhCSF + g * 8;
+#ifdef PCLSEG_R4X
     // Software-pipelined over the (K-step, row) groups: the two fragment reads of group k + 1 are issued BEFORE the
     // six MFMAs of group k and land while those run (hipcc, left alone, emitted `2 reads, wait, 6 MFMAs` per
     // group: ~100 cycles of LDS latency in front of every 96 cycles of matrix work, 36 times per wave).  A
@@ -1512,6 +1547,27 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     };
     sweep(0, 4);
     if (wave + 16 < 18) sweep(4, 5);   // wave-uniform
+#else
+#pragma unroll
+    for (int i = 0; i < kHdSteps; ++i) {
+      const int st = wave + 4 * i;
+      if (st < 18) {   // wave-uniform
+        const int tap = st >> 1, ti = (tap * 11) >> 5, tj = tap - 3 * ti;
+        const int koff = fbase + (ti * kFhFW + tj) * kFhCSF + (st & 1) * 32;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const f16x8 xh = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF));
+          const f16x8 xl = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF) + 64);
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) {
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl[i][t], xh, acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xl, acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xh, acc[r][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+#endif
     stamp(6);
     // partial sums -> LDS [wave][row][tile][lane] (F and U are dead once every wave is here)
     f32x4* part = reinterpret_cast<f32x4*>(smem_raw);
@@ -2046,6 +2102,24 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
 #pragma unroll
   for (int nn = 0; nn < (SQ > 0 ? SQ : 1); ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float vmax = 0.f;
+#ifdef PCLSEG_R4X
+  // fused squeeze: a chunk's weight fragments are requested one gate pass AHEAD of their MFMAs (they were fetched
+  // right in front of them: NCH * CK/32 exposed L2 round trips per block, in a kernel whose blocks are short
+  // chains of dependent phases; all chunks at once costs 16 more registers than the 128 this kernel may use)
+  constexpr int kSqSteps = CK / 32, kSqT = SQ > 0 ? SQ : 1;
+  f16x8 swh[kSqSteps][kSqT], swl[kSqSteps][kSqT];
+  auto load_sqw = [&](const int chunk) {
+#pragma unroll
+    for (int t = 0; t < kSqSteps; ++t)
+#pragma unroll
+      for (int nn = 0; nn < kSqT; ++nn) {
+        const _Float16* wp = a.sq_w16 + ((size_t)(chunk * kSqSteps + t) * kSqT + nn) * 1024 + lane * 8;
+        swh[t][nn] = *reinterpret_cast<const f16x8*>(wp);
+        swl[t][nn] = *reinterpret_cast<const f16x8*>(wp + 512);
+      }
+  };
+  if constexpr (SQ > 0) load_sqw(0);
+#endif
 #pragma unroll
   for (int chunk = 0; chunk < NCH; ++chunk) {
     if (active) {
@@ -2094,18 +2168,32 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
         for (int t = 0; t < CK / 32; ++t) {
           const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + t * 32);
           const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + t * 32 + CK);
+#ifdef PCLSEG_R4X
+#pragma unroll
+          for (int nn = 0; nn < SQ; ++nn) {
+            const f16x8 wh = swh[t][nn], wl = swl[t][nn];
+#else
           const _Float16* wp = a.sq_w16 + ((size_t)(chunk * (CK / 32) + t) * SQ) * 1024 + lane * 8;
 #pragma unroll
           for (int nn = 0; nn < SQ; ++nn) {
             const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
             const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+#endif
             acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[nn], 0, 0, 0);
             acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[nn], 0, 0, 0);
             acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[nn], 0, 0, 0);
           }
         }
       }
+#ifdef PCLSEG_R4X
+      if (chunk + 1 < NCH) {
+        asm volatile("" ::: "memory");   // (the next chunk's fragments: requested AFTER this chunk's MFMAs have read theirs)
+        load_sqw(chunk + 1);
+        __syncthreads();
+      }
+#else
       if (chunk + 1 < NCH) __syncthreads();
+#endif
     }
   }
   if constexpr (SQ > 0) {
