@@ -8,7 +8,7 @@ SRCS  := $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h $(CSRC)/pclseg_api.hip 
 # (pclseg_build_sha): bench.py compares it with the sources next to it and refuses to quote a PMC
 # traffic figure when the binary that ran was built from something else
 SRC_SHA := $(shell cat $(SRCS) | sha256sum | cut -c1-16)
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -DPCLSEG_SRC_SHA=\"$(SRC_SHA)\"
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -DPCLSEG_SRC_SHA=\"$(SRC_SHA)\" $(EXTRA)
 
 all: $(LIB)
 

@@ -147,8 +147,10 @@ int pclseg_plan(const pclseg_desc* desc, pclseg_plan_info* out);
 
 /* Names of the kernel launches a desc plans, in launch order, one per line ("conv1", "cam1",
  * "pool+fire2/squeeze", "fire4/expand+fire5/squeeze", "enc3/residual_1/conv2", ...), each followed by a TAB and
- * the multiply-accumulates per scan of that launch: labels and FLOP counts for per-operator profiles (the
- * pre-processing launch that precedes them is not in the list).  Runs without a GPU. */
+ * the multiply-accumulates per scan of that launch, then TAB-separated the static launch resources of the
+ * split-f16 plan — dynamic LDS bytes per block, threads per block, blocks per scan: labels, FLOP counts and
+ * co-residency limits for per-operator profiles (the pre-processing launch that precedes them is not in the
+ * list).  Runs without a GPU. */
 int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap);
 
 /* Build the model graph on desc->device: replaces constructing the Keras model

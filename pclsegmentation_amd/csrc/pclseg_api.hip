@@ -1503,7 +1503,52 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
       if (op.fsq_fused) macs += hw * (op.sub[0].cout + op.sub[1].cout) * op.fsq.cout;
       if (op.head_fused) macs += hw * 9 * 64 * op.hd.cout;
     }
-    out += nm + "\t" + std::to_string(macs) + "\n";
+    // static launch resources of the split-f16 plan (what decides which kernels can share a CU): dynamic LDS
+    // bytes per block, threads per block, blocks per scan — the same expressions the launchers use
+    int64_t lds = 0, threads = 256, blocks = 0;
+    if (op.kind == OP_CAM) {
+      const int R = op.cin_t / 16;
+      lds = (int64_t)(4 * kCamPW * 64 + 64 * R) * 4;
+      if (op.fsq_fused) lds = std::max<int64_t>(lds, ((4 * kCamTW * R * 4 + 15) & ~15) + (int64_t)((4 * kCamTW + 15) / 16) * 16 * (2 * 64 + kPadF16) * 2);
+      threads = 512;
+      blocks = (int64_t)((ti.H + 3) / 4) * ((ti.W + kCamTW - 1) / kCamTW);
+    } else if (op.kind == OP_POOL) {
+      blocks = ((int64_t)ti.H * ti.W * ti.C / 4 + 255) / 256 / 4;
+    } else if (op.head_fused) {
+      lds = kFhLds;
+      blocks = (int64_t)((ti.H + kFhTH - 1) / kFhTH) * (2 * ti.W / kFhTW);
+    } else if (op.pool_fused) {
+      int wo2, pl2;
+      same_pad(ti.W, 3, 2, &wo2, &pl2);
+      lds = (int64_t)kPoolSqRows * 16 * (2 * op.cin_t + kPadF16) * 2;
+      blocks = (int64_t)((ti.H + kPoolSqRows - 1) / kPoolSqRows) * ((wo2 + 15) / 16);
+    } else {
+      const bool direct = op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.cin_t % 8 == 0 && op.ck16 >= 32 &&
+                          op.sk_in < 0 && op.res2 < 0 && g.tensors[op.in].fmt != FMT_S16 && op.sub[0].nctp <= 4;
+      const TileGeom t = tile_geom(op);
+      const int Wc = op.up_fused ? 2 * ti.W : ti.W;
+      int wo2, pl2;
+      same_pad(Wc, op.pkw, op.sw, &wo2, &pl2);
+      const int wconv = op.ow_mul == 2 ? Wc : wo2;
+      threads = op.nw * 64;
+      if (direct) {
+        const bool splitk = op.cin_t >= 256 && op.sub[0].nctp >= 3;
+        lds = splitk ? (int64_t)4 * 2 * op.sub[0].nctp * 1024 : 0;
+        const int px = splitk ? 32 : 4 * (op.sub[0].nctp == 4 ? 1 : 2) * 16;
+        blocks = ((int64_t)ti.H * ti.W + px - 1) / px;
+      } else {
+        lds = (lds_bytes_f16(op, op.ck16) + 15) & ~(int64_t)15;
+        if (op.sk_in >= 0) lds += (int64_t)9 * g.tensors[op.out].C * 4;
+        if (op.up_fused) lds = ((lds + 15) & ~(int64_t)15) + (int64_t)t.PH * (t.PW / 2 + 1) * (2 * op.cin_t + kPadF16) * 2;
+        if (op.fsq_fused) lds = std::max<int64_t>(lds, (int64_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * 4);
+        int ny = 0;
+        for (int i = 0; i < op.nsub; ++i) ny += op.sub[i].nctp / (op.ntw * op.wn);
+        if (op.pair) ny = op.sub[1].nctp / (op.ntw * op.wn);
+        blocks = op_is_flat(op) ? (((int64_t)ti.H * ti.W + t.SEGW * 16 - 1) / (t.SEGW * 16)) * std::max(ny, 1)
+                                : (int64_t)((ti.H + t.TH - 1) / t.TH) * ((wconv + t.SEGW * 16 - 1) / (t.SEGW * 16)) * std::max(ny, 1);
+      }
+    }
+    out += nm + "\t" + std::to_string(macs) + "\t" + std::to_string(lds) + "\t" + std::to_string(threads) + "\t" + std::to_string(blocks) + "\n";
   }
   if (out.size() + 1 > cap) return fail(nullptr, PCLSEG_ERR_BAD_ARG, fmt("buffer of %zu bytes, the op list needs %zu", cap, out.size() + 1));
   memcpy(buf, out.c_str(), out.size() + 1);

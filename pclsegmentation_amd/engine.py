@@ -205,6 +205,13 @@ def plan_op_macs(desc):
   return [(l.split("\t")[0], int(l.split("\t")[1])) for l in buf.value.decode().splitlines()]
 
 
+def plan_op_resources(desc):
+  """CPU-only: [(launch name, MACs per scan, LDS bytes per block, threads per block, blocks per scan)]."""
+  buf = ctypes.create_string_buffer(1 << 16)
+  check(load_library().pclseg_plan_ops(ctypes.byref(desc), buf, len(buf)))
+  return [(f[0],) + tuple(int(x) for x in f[1:5]) for f in (l.split("\t") for l in buf.value.decode().splitlines())]
+
+
 def _host_f32(a):
   return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 

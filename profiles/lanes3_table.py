@@ -5,6 +5,8 @@ usage: lanes3_table.py <dir with kt1/ kt3/ pmc1_<i>/ pmc3_<i>/>
 A lane is a HIP stream (Stream_Id of the kernel trace); within a lane the launches follow the plan's
 sequence (pclseg_plan_ops, +1 for the pre-processing launch), so launch k of a lane is operator k mod len(plan).
 
+Section 0  static residency of every launch: LDS bytes and threads per block (pclseg_plan_ops), registers per lane
+           (kernel trace), hence blocks per CU and what is left of a CU beside them — which kernels CAN share a CU.
 Section 1  job level: kernel time per scan, wall time per scan, kernels in flight, at 1 and at 3 lanes.
 Section 2  per operator: duration alone (1 lane) and among the other lanes' kernels (3 lanes), the inflation,
            the time-weighted number of OTHER kernels running beside it, and the operator it overlaps most.
@@ -32,7 +34,8 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "ssv2_64x2048"
 model_name, config_name, h, w, batch, _, _ = bench.WORKLOADS[wl]
 mc, model = P.load_model_config(model_name, config_name, height=h, width=w)
 desc = model.engine_desc(h, w)
-ops = ["preprocess"] + [n for n, _ in E.plan_op_macs(desc)]
+res = [("preprocess", 0, 0, 256, 0)] + E.plan_op_resources(desc)
+ops = [r[0] for r in res]
 mb = E.plan(desc)["micro_batch"]
 per = len(ops)
 
@@ -73,7 +76,8 @@ def trace(sub):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     for k, r in enumerate(rows):
       out.append({"op": k % per, "lane": sid, "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"]),
-                  "id": int(r["Dispatch_Id"]), "name": r["Kernel_Name"]})
+                  "id": int(r["Dispatch_Id"]), "name": r["Kernel_Name"], "vgpr": int(r.get("VGPR_Count") or 0),
+                  "blocks": int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))})
   out.sort(key=lambda r: r["t0"])
   return out
 
@@ -120,6 +124,36 @@ def overlaps(rows):
 
 k1, k3 = trace("kt1"), trace("kt3")
 print("# %s: micro-batch %d scans, %d launches per micro-batch (%s)" % (wl, mb, per, d))
+print("\n## 0. static residency per launch (a CU: 160 KiB LDS, 4 SIMDs x 512 registers per lane x 8 wave slots)")
+print("%-34s %7s %7s %5s %6s %9s %10s %14s" % ("op", "blocks", "LDS KB", "thr", "VGPRs", "blocks/CU", "limited by", "left on the CU"))
+# registers per lane: the compiler's own figure (profiles/rNN_kernel_resources.txt from scripts/resources.sh),
+# matched by kernel name; fallback 2 x the trace CSV's VGPR_Count (it counts register pairs on gfx950)
+import re
+regs = {}
+for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_resources.txt"))):
+  for line in open(f):
+    m = re.match(r"(.*?)\s+vgpr=\s*(\d+)", line)
+    if m:
+      regs[re.sub(r"\s+", "", m.group(1).replace("void ", ""))] = int(m.group(2))
+def regs_of(kname, csv_count):
+  key = re.sub(r"\s+", "", kname.replace("void ", "").replace("pclseg::", "").split("(")[0])
+  for k, v in regs.items():
+    if k.split("(")[0] == key:
+      return -(-v // 8) * 8        # allocation granule: 8
+  return 2 * csv_count
+vg = {}
+for r in k1:
+  vg.setdefault(r["op"], (regs_of(r["name"], r["vgpr"]), r["blocks"]))
+for i, (name, macs, lds, thr, bps) in enumerate(res):
+  v, blocks = vg.get(i, (0, 0))
+  wps = thr // 64 / 4.0                                    # waves per SIMD of one block
+  by_lds = 163840 // lds if lds else 99
+  by_vgpr = int((512 // max(v, 1)) // max(wps, 0.25)) if v else 99
+  by_waves = int(8 // max(wps, 0.25))
+  n = max(1, min(by_lds, by_vgpr, by_waves, 8))
+  lim = "LDS" if n == by_lds else "registers" if n == by_vgpr else "wave slots"
+  left = "%3d KB, %3d regs" % ((163840 - n * lds) // 1024, 512 - int(n * wps * v))
+  print("%-34s %7d %7.1f %5d %6d %9d %10s %16s" % (name[:34], blocks, lds / 1024.0, thr, v, n, lim, left))
 print("\n## 1. job level")
 print("%-8s %14s %14s %10s" % ("lanes", "kernel us/scan", "wall us/scan", "in flight"))
 j1, j3 = job(k1), job(k3)

@@ -8,7 +8,7 @@ import sys
 txt = open(sys.argv[1]).read()
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
 for b in blocks:
-  name = b.split("\n")[0].strip()
+  name = b.split("\n")[0].strip().split()[0]
 
   def g(k):
     m = re.search(k + r": (\d+)", b)
@@ -17,6 +17,6 @@ for b in blocks:
     nm = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
   except FileNotFoundError:
     nm = name
-  nm = nm.replace("pclseg::", "").replace("(pclseg::ConvArgs)", "").replace("(ConvArgs)", "")[:64]
-  print("%-66s vgpr=%3d agpr=%3d scratch=%4d occ=%d sgpr=%3d" % (
+  nm = nm.replace("pclseg::", "").replace("(pclseg::ConvArgs)", "").replace("(ConvArgs)", "")[:110]
+  print("%-112s vgpr=%3d agpr=%3d scratch=%4d occ=%d sgpr=%3d" % (
     nm, g("VGPRs"), g("AGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"), g("SGPRs")))
