@@ -613,6 +613,29 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     static const int gm = tune_env("PCLSEG_GROUP_MAJOR", -1);
     a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
   }
+#ifdef PCLSEG_R4X
+  // Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): the software-pipelined GEMM kernel
+  if (!exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.ck16 == 64 && op.cin_t % 128 == 0 &&
+      op.sub[0].nctp % 8 == 0 && op.sub[0].cout == op.sub[0].nctp * 16 && !a.in_s16 && !a.res1 && !a.res2 && !a.skx && w16) {
+    static const int wide_on = tune_env("PCLSEG_WIDE1X1", 1);
+    if (wide_on) {
+      const int nt = op.sub[0].nctp % 16 == 0 ? 2 : 1;
+      const int ny_w = op.sub[0].nctp / (8 * nt);
+      a.ny = ny_w;
+      a.sub[0].ny = ny_w;
+      if (ny_w == 1) a.group_major = 0;
+      const dim3 wgrid((unsigned)(((a.Win + kW1Px - 1) / kW1Px) * ny_w));
+      if (nt == 2) {
+        if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&conv1x1_wide_kernel<2>), kW1Lds)) return e;
+        hipLaunchKernelGGL((conv1x1_wide_kernel<2>), wgrid, dim3(512), kW1Lds, s, a);
+      } else {
+        if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(&conv1x1_wide_kernel<1>), kW1Lds)) return e;
+        hipLaunchKernelGGL((conv1x1_wide_kernel<1>), wgrid, dim3(512), kW1Lds, s, a);
+      }
+      return hipGetLastError();
+    }
+  }
+#endif
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
 #ifdef PCLSEG_WITH_STAMPS
   StampDump stamp_dump(op.name(), &a.stamps, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split

@@ -1595,6 +1595,194 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
 
+#ifdef PCLSEG_R4X
+// ---- Wide 1x1 convolutions (Darknet's BasicBlock / decoder-block conv1: 128-1024 -> 64-1024 channels), split-f16.
+// Reference: nets/Darknet.py:34-43 (conv1 1x1 + bn1 + LeakyReLU of BasicBlock).
+// conv_kernel runs them as `stage a 64-channel chunk -> barrier -> 2 K-steps -> barrier`: a chunk's matrix work is
+// 96 MFMAs per wave (1.5 k cycles) between two memory round trips that nothing overlaps (3x3 layers amortise the
+// same per-chunk cost over 18 K-steps): 13-31 % of the matrix rate on 1.7 ms of Darknet-53's 10.5 ms micro-batch.
+// This kernel is the same GEMM (D[cout][pixel], packed fragments of conv_kernel, 64-channel chunks) as a software
+// pipeline in which NO wave waits for a memory round trip in steady state:
+//   - 8 waves, 128 pixels x 8*NT cout tiles per block; wave w owns cout tiles {NT w ..} for all 8 pixel segments;
+//   - activations: the float4 units of chunk c + 2 are requested (4 per thread) BEFORE the K loop of chunk c, split
+//     to hi/lo and written to LDS after the K loop of chunk c + 1; TWO LDS buffers, so ONE barrier per chunk (the
+//     buffer written in iteration c + 1 was last read in iteration c - 1, before that iteration's barrier);
+//   - weights: the fragments of chunk c + 1 (both K-steps) are requested before the K loop of chunk c;
+//   - barriers are `s_waitcnt lgkmcnt(0); s_barrier`: they leave the prefetches in flight.
+// One block per CU (<= 256 registers, 68 KB of LDS).  Flat pixels: a.Win = N*H*W, a.Cin % 128 == 0 (an even number
+// of chunks: the loop is unrolled by two so every prefetch register set has a fixed name), no residual operands.
+constexpr int kW1Px = 128, kW1CS = 2 * 64 + kPadF16;                 // pixels per block; halfs per staged pixel [hi 64 | lo 64 | pad]
+constexpr int kW1Buf = kW1Px * kW1CS;                                // halfs per LDS buffer
+constexpr int kW1Lds = 2 * kW1Buf * 2;                               // bytes
+template <int NT>
+__global__ __launch_bounds__(512, 2) void conv1x1_wide_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* sm = reinterpret_cast<_Float16*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  const ConvSub& S = a.sub[0];
+  const int total = a.Win;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int tile, by;
+  if (a.group_major) {
+    const int ntiles = gridDim.x / a.ny;
+    by = lid / ntiles;
+    tile = lid - by * ntiles;
+  } else {
+    tile = lid / a.ny;
+    by = lid - tile * a.ny;
+  }
+  const int pix0 = tile * kW1Px;
+  const int ct0 = (by * 8 + wave) * NT;
+  const int nch = a.Cin >> 6;
+  float vmax = 0.f;
+
+  // staging: thread <-> (channel quad u of the chunk, pixels sp0 + 32 k): a wave covers 4 pixels x 256 contiguous bytes
+  const int u = tid & 15, sp0 = tid >> 4;
+  const float* src[4];
+  bool sok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = pix0 + sp0 + 32 * k;
+    sok[k] = px < total;
+    src[k] = a.in + (size_t)(sok[k] ? px : 0) * a.Cin + u * 4;
+  }
+  auto load_acts = [&](const int c, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(src[k] + c * 64);
+  };
+  auto store_acts = [&](f32x4 (&v)[4], _Float16* const buf) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!sok[k]) v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f16x4 hi, lo;
+      split4(v[k], hi, lo);
+      vmax = absmax4(vmax, v[k]);
+      _Float16* d = buf + (sp0 + 32 * k) * kW1CS + u * 4;
+      *reinterpret_cast<f16x4*>(d) = hi;
+      *reinterpret_cast<f16x4*>(d + 64) = lo;
+    }
+  };
+  const _Float16* wbase = S.w16 + (size_t)ct0 * 1024 + lane * 8;
+  const unsigned wstep = (unsigned)S.nctp * 1024u;
+  // weight fragments: ONE register set per K-step of a chunk; a set is re-requested for the NEXT chunk as soon as its
+  // K-step's MFMAs are issued (a chunk's matrix work = 1.5 k cycles per wave x 2 waves per SIMD covers the L2 trip)
+  f16x8 wh[2][NT], wl[2][NT];
+  auto load_w = [&](const int c, const int st) {
+    const _Float16* wp = wbase + (size_t)(2 * c + st) * wstep;
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+      wh[st][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+      wl[st][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+    }
+  };
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int xoff = p * kW1CS + g * 8;
+  // A chunk's K loop = 4 half-steps (K-step st = h / 2, segments 4 (h & 1) ..): the 8 fragment reads of half-step
+  // h + 1 are issued BEFORE the 12 NT MFMAs of half-step h (two register sets), pinned by scheduling-group barriers:
+  // left alone the scheduler emits `2 reads, wait, 6 MFMAs` and sinks every prefetch to just before its use.
+  auto kloop = [&](const _Float16* const buf, const int cnext) {   // cnext: the chunk whose fragments to request next
+    f16x8 xh[2][4], xl[2][4];
+    auto rd = [&](const int h, const int slot) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const _Float16* xp = buf + xoff + (4 * (h & 1) + m) * (16 * kW1CS) + (h >> 1) * 32;
+        xh[slot][m] = *reinterpret_cast<const f16x8*>(xp);
+        xl[slot][m] = *reinterpret_cast<const f16x8*>(xp + 64);
+      }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int st = h >> 1, m0 = 4 * (h & 1), slot = h & 1;
+      if (h + 1 < 4) rd(h + 1, slot ^ 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+          acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[st][nn], xh[slot][m], acc[m0 + m][nn], 0, 0, 0);
+          acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][nn], xl[slot][m], acc[m0 + m][nn], 0, 0, 0);
+          acc[m0 + m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[st][nn], xh[slot][m], acc[m0 + m][nn], 0, 0, 0);
+        }
+      if (h + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12 * NT, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (h & 1) {                          // K-step st is done with its fragments
+        load_w(cnext, st);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- prologue: chunks 0 and 1 requested, chunk 0 staged
+  f32x4 vA[4], vB[4];
+  load_acts(0, vA);
+  load_w(0, 0);
+  load_w(0, 1);
+  load_acts(1, vB);
+  store_acts(vA, sm);
+  lds_barrier();
+  // ---- steady state, two chunks per trip (nch is even): chunk c from buffer 0, chunk c + 1 from buffer 1; vA / vB
+  // carry the activations of chunks c + 2 / c + 3 across the K loops
+  // (every prefetch is unconditional — past the last chunk it re-requests chunk nch - 1 and nobody reads it: a
+  // branch around a request makes the compiler's wait-count pass join two histories and wait for everything)
+  const int last = nch - 1;
+  for (int c = 0; c < nch; c += 2) {
+    load_acts(c + 2 < nch ? c + 2 : last, vA);
+    __builtin_amdgcn_sched_barrier(0);      // (the requests stay HERE, ahead of the K loop they are hidden behind)
+    kloop(sm, c + 1);
+    store_acts(vB, sm + kW1Buf);            // chunk c + 1 (requested one trip ago)
+    lds_barrier();
+    load_acts(c + 3 < nch ? c + 3 : last, vB);
+    __builtin_amdgcn_sched_barrier(0);
+    kloop(sm + kW1Buf, c + 2 < nch ? c + 2 : last);
+    if (c + 2 < nch) {
+      store_acts(vA, sm);                   // chunk c + 2
+      lds_barrier();
+    }
+  }
+
+  // ---- epilogue: bias (+ inverse weight scale), activation, float32 or split-f16 store
+  {
+    f32x4 bv[NT];
+    float iv[NT];
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+      bv[nn] = *reinterpret_cast<const f32x4*>(S.bias + (ct0 + nn) * 16 + g * 4);
+      iv[nn] = sload(S.bias + (S.nctp + ct0 + nn) * 16);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int px = pix0 + m * 16 + p;
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn) {
+        const int co = (ct0 + nn) * 16 + g * 4;
+        if (px < total && co < S.Cout) {
+          const f32x4 v = act4(fma4(acc[m][nn], iv[nn], bv[nn]), S.act);
+          if (a.out_s16) {
+            f16x4 hi, lo;
+            split4(v, hi, lo);
+            vmax = absmax4(vmax, v);
+            _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + (size_t)px * (size_t)(2 * a.out_C) + S.co_off + co;
+            *reinterpret_cast<f16x4*>(o16) = hi;
+            *reinterpret_cast<f16x4*>(o16 + a.out_C) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(a.out + (size_t)px * a.out_C + S.co_off + co) = v;
+          }
+        }
+      }
+    }
+  }
+  if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
+}
+#endif  // PCLSEG_R4X
+
 // ---- 1x1 convolutions without LDS (split-f16 mode).
 // A 1x1 conv has no halo, so staging its input through LDS only buys the hi/lo split and costs two
 // block barriers per channel chunk plus the LDS footprint.  Here every wave is an independent

@@ -71,6 +71,12 @@ CONV_CASES = [
   (1, 8, 16, 48, 192, 3, 1, "relu", True, True, True),       # partial last chunk (48 = 32+16)
   (1, 8, 16, 256, 512, 3, 1, "leaky", False, True, True),    # darknet-sized
   (1, 3, 130, 4, 20, 1, 1, "none", True, False, False),      # cout 20 -> padded tile
+  # Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): flat pixels, 128-pixel tiles (ragged last tile),
+  # 2 .. 16 channel chunks, one and two cout groups
+  (1, 8, 40, 256, 128, 1, 1, "leaky", False, True, False),   # enc3-like: 8 cout tiles, 320 px = 2.5 tiles
+  (2, 4, 33, 128, 256, 1, 1, "leaky", False, True, False),   # dec3-like: 2 chunks, 16 cout tiles, 264 px
+  (1, 4, 96, 1024, 512, 1, 1, "leaky", False, True, False),  # enc5-like: 16 chunks, 2 cout groups, 3 tiles
+  (1, 2, 64, 512, 1024, 1, 1, "leaky", True, True, False),   # dec5-like: 4 cout groups, exactly one tile
 ]
 
 
