@@ -593,7 +593,11 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   }
   if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
     if (exact) return hipErrorInvalidValue;
-    lds = std::max(lds, (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float));   // rows padded by 4 floats
+    size_t slab = (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float);   // rows padded by 4 floats
+#ifdef PCLSEG_R4X
+    if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (size_t)8 * op.mtw * 16 * (2 * 16 + 4) * sizeof(float);   // two passes (conv_kernel NPASS)
+#endif
+    lds = std::max(lds, slab);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
   } else if (lds > 64 * 1024) return hipErrorInvalidValue;
   // (the fused-skip-branch epilogue of fire13 needs more registers than the merged kernel has left)

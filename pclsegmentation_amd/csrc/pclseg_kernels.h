@@ -1000,6 +1000,50 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
         // Slab rows are padded by 4 floats: with Q a multiple of 16 the 8 consecutive pixels one
         // ds_write_b128 lane group covers would otherwise all start in the same bank (rows 64..256 B
         // apart: an 8- to 16-way conflict that made this phase 29 % of the block).
+#ifdef PCLSEG_R4X
+        constexpr int Q = FSQ * 16, PXW = MTW * 16;
+        // (round 4, -DPCLSEG_R4X) the 136 KB slab of fire8/9 goes through LDS in TWO passes of half the squeeze
+        // tiles: 70 KB per block, so that a block of another lane's memory-bound kernel can share the CU
+        // (profiles/r04_ssv2_3lane_counters.txt: a 136 KB block is placed only on an EMPTY CU)
+        constexpr int NPASS = (FSQ == 4 && NW * PXW * (Q + 4) * 4 > 96 * 1024) ? 2 : 1;
+        constexpr int FQ = FSQ / NPASS, QP = FQ * 16, QS = QP + 4;
+        float* slab = reinterpret_cast<float*>(smem_raw);
+        constexpr int WMc = NW / WN, QQ = QP / 4;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          __syncthreads();
+#pragma unroll
+          for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int qt = 0; qt < FQ; ++qt)
+              *reinterpret_cast<f32x4*>(slab + ((size_t)(wave * PXW + m * 16 + p) * QS + qt * 16 + 4 * g)) = acc2[m][pass * FQ + qt];
+          __syncthreads();
+          for (int idx = tid; idx < WMc * PXW * QQ; idx += kThreads) {
+            const int px = idx / QQ, qq = idx - px * QQ;
+            const int wmi = px / PXW, pl = px - wmi * PXW;
+            const int qg = pass * QP + qq * 4;   // squeeze channel of this quad
+            f32x4 sum = *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN) * PXW + pl) * QS + qq * 4));
+#pragma unroll
+            for (int w = 1; w < WN; ++w)
+              sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * QS + qq * 4));
+            sum = fma4(sum, a.fsq_bias[Q + (qg & ~15)], *reinterpret_cast<const f32x4*>(a.fsq_bias + qg));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.0f);
+            const int seg = wmi * MTW + (pl >> 4), pp = pl & 15;
+            const int sr = seg / a.SEGW;
+            const int oh = h0 + sr, j = w0 + (seg - sr * a.SEGW) * 16 + pp;
+            if (oh < a.H && j < a.Wconv) {
+              f16x4 hi, lo;
+              split4(sum, hi, lo);
+              vmax = absmax4(vmax, sum);
+              _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + (((size_t)n * a.H + oh) * a.Wout + j) * (size_t)(2 * Q) + qg;
+              *reinterpret_cast<f16x4*>(o16) = hi;
+              *reinterpret_cast<f16x4*>(o16 + Q) = lo;
+            }
+          }
+        }
+      }
+#else
         constexpr int Q = FSQ * 16, PXW = MTW * 16, QS = Q + 4;
         float* slab = reinterpret_cast<float*>(smem_raw);
         __syncthreads();
@@ -1033,6 +1077,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
           }
         }
       }
+#endif
     } else if constexpr (LW > 0) {
       // two LDS buffers; loaders fill buffer (c + 1) & 1 while the compute waves read buffer c & 1.  Barrier
       // #c (c = 0 .. nchunks - 1) is passed by the loaders after staging chunk c and by the compute waves
