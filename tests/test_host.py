@@ -255,6 +255,17 @@ def test_plan_ops_lists_every_launch_with_its_macs(arch, cfg, h, w):
     assert len(names) == 19                      # + the pre-processing launch = 20 per micro-batch
   else:
     assert names[-1] == "head+head" and "enc5/residual_0/conv2" in names
+  # static launch resources (round 4: what decides which kernels can share a CU): every block fits a CU's 160 KB of
+  # LDS, has 256 or 512 threads and at least one block per scan; the figures the three-lane analysis quotes
+  res = E.plan_op_resources(d)
+  assert [r[0] for r in res] == names and [r[1] for r in res] == [m for _, m in ops]
+  for name, _, lds, threads, blocks in res:
+    assert 0 <= lds <= 160 * 1024 and threads in (256, 512) and blocks >= 1, (name, lds, threads, blocks)
+  if arch == "squeezesegv2":
+    by = {r[0]: r for r in res}
+    assert by["fire8/expand+fire9/squeeze"][2:] == (139264, 512, 128)      # one 136 KB block per CU
+    assert by["up+fire13/expand+conv14+head"][2:] == (71424, 256, 1024)    # two 70 KB blocks per CU
+    assert by["conv1"][4] == 512 and by["cam1"][3] == 512
 
 
 _OOM_CHILD = r"""
