@@ -16,3 +16,5 @@ for lib in "" "PCLSEG_LIB=$R4X" "" "PCLSEG_LIB=$R4X"; do
   done
 done > gpurun_out/r04_run2_dn.log 2>&1
 cat gpurun_out/r04_run2_dn.log
+# the driver's own command on the shipped library: the whole bench line (five regions, spread, build, c1_gpu, parity_check)
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_run2_bench.json 2> gpurun_out/r04_run2_bench.err; tail -c 3000 gpurun_out/r04_run2_bench.json; tail -3 gpurun_out/r04_run2_bench.err
