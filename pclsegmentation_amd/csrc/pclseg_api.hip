@@ -619,7 +619,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   }
 #ifdef PCLSEG_R4X
   // Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): the software-pipelined GEMM kernel
-  if (!exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.ck16 == 64 && op.cin_t % 128 == 0 &&
+  if (!exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.ck16 == 64 && op.cin_t % 64 == 0 && op.cin_t >= 128 &&
       op.sub[0].nctp % 8 == 0 && op.sub[0].cout == op.sub[0].nctp * 16 && !a.in_s16 && !a.res1 && !a.res2 && !a.skx && w16) {
     static const int wide_on = tune_env("PCLSEG_WIDE1X1", 1);
     if (wide_on) {

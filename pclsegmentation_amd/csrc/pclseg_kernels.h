@@ -1649,13 +1649,14 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
 // This kernel is the same GEMM (D[cout][pixel], packed fragments of conv_kernel, 64-channel chunks) as a software
 // pipeline in which NO wave waits for a memory round trip in steady state:
 //   - 8 waves, 128 pixels x 8*NT cout tiles per block; wave w owns cout tiles {NT w ..} for all 8 pixel segments;
-//   - activations: the float4 units of chunk c + 2 are requested (4 per thread) BEFORE the K loop of chunk c, split
-//     to hi/lo and written to LDS after the K loop of chunk c + 1; TWO LDS buffers, so ONE barrier per chunk (the
-//     buffer written in iteration c + 1 was last read in iteration c - 1, before that iteration's barrier);
-//   - weights: the fragments of chunk c + 1 (both K-steps) are requested before the K loop of chunk c;
+//   - activations: the float4 units of chunk c + 1 are requested (4 per thread) BEFORE the K loop of chunk c, split
+//     to hi/lo and written to the OTHER LDS buffer after it: TWO buffers, so ONE barrier per chunk (the buffer
+//     written after K loop c was last read in K loop c - 1, before the barrier of that iteration);
+//   - weights: each K-step's fragments are re-requested for chunk c + 1 as soon as their MFMAs of chunk c are issued;
+//   - fragment reads run one half-step ahead of the MFMAs (two register sets, scheduling-group barriers);
 //   - barriers are `s_waitcnt lgkmcnt(0); s_barrier`: they leave the prefetches in flight.
-// One block per CU (<= 256 registers, 68 KB of LDS).  Flat pixels: a.Win = N*H*W, a.Cin % 128 == 0 (an even number
-// of chunks: the loop is unrolled by two so every prefetch register set has a fixed name), no residual operands.
+// One block per CU (<= 256 registers, 68 KB of LDS).  Flat pixels: a.Win = N*H*W, a.Cin % 64 == 0, float32 input,
+// no residual operands.
 constexpr int kW1Px = 128, kW1CS = 2 * 64 + kPadF16;                 // pixels per block; halfs per staged pixel [hi 64 | lo 64 | pad]
 constexpr int kW1Buf = kW1Px * kW1CS;                                // halfs per LDS buffer
 constexpr int kW1Lds = 2 * kW1Buf * 2;                               // bytes
@@ -1765,30 +1766,29 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wide_kernel(const ConvArgs a) 
     }
   };
 
-  // ---- prologue: chunks 0 and 1 requested, chunk 0 staged
-  f32x4 vA[4], vB[4];
-  load_acts(0, vA);
+  // ---- prologue: chunk 0 staged, its fragments requested
+  f32x4 v[4];
+  load_acts(0, v);
   load_w(0, 0);
   load_w(0, 1);
-  load_acts(1, vB);
-  store_acts(vA, sm);
+  store_acts(v, sm);
   lds_barrier();
-  // ---- steady state, two chunks per trip (nch is even): chunk c from buffer 0, chunk c + 1 from buffer 1; vA / vB
-  // carry the activations of chunks c + 2 / c + 3 across the K loops
+  // ---- steady state.  vmcnt retires in issue order, so a request is waited for as soon as anything issued AFTER
+  // it is needed: the activations of chunk c + 1 go out before the K loop of chunk c (whose own fragments are
+  // older) and are consumed right after it — one K loop (2 waves per SIMD x 96 MFMAs) of cover, with no younger
+  // request needed in between; the fragments of chunk c + 1 go out inside that K loop, behind them.
   // (every prefetch is unconditional — past the last chunk it re-requests chunk nch - 1 and nobody reads it: a
   // branch around a request makes the compiler's wait-count pass join two histories and wait for everything)
   const int last = nch - 1;
-  for (int c = 0; c < nch; c += 2) {
-    load_acts(c + 2 < nch ? c + 2 : last, vA);
+  for (int c = 0; c < nch; ++c) {
+    const int cn = c + 1 < nch ? c + 1 : last;
+    _Float16* const cur = sm + (c & 1) * kW1Buf;
+    _Float16* const nxt = sm + ((c + 1) & 1) * kW1Buf;
+    load_acts(cn, v);
     __builtin_amdgcn_sched_barrier(0);      // (the requests stay HERE, ahead of the K loop they are hidden behind)
-    kloop(sm, c + 1);
-    store_acts(vB, sm + kW1Buf);            // chunk c + 1 (requested one trip ago)
-    lds_barrier();
-    load_acts(c + 3 < nch ? c + 3 : last, vB);
-    __builtin_amdgcn_sched_barrier(0);
-    kloop(sm + kW1Buf, c + 2 < nch ? c + 2 : last);
-    if (c + 2 < nch) {
-      store_acts(vA, sm);                   // chunk c + 2
+    kloop(cur, cn);
+    if (c + 1 < nch) {
+      store_acts(v, nxt);                   // (last read two K loops ago, with a barrier in between)
       lds_barrier();
     }
   }
