@@ -1482,6 +1482,65 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     }
     stamp(4);
     asm volatile("" ::: "memory");
+#ifdef PCLSEG_R4X
+    // (round 4) the epilogue's own operands — the skip branch's fragments and the two bias quads of each cout tile —
+    // are requested HERE, together, into the registers the expand fragments have just left; they were fetched inside
+    // the per-tile loop right in front of their use: four L2 round trips in a row per block
+    f16x8 kwhA[4], kwlA[4];
+    f32x4 bvA[4], kbA[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      kwhA[t] = *reinterpret_cast<const f16x8*>(a.sk_w16 + t * 1024 + lane8);
+      kwlA[t] = *reinterpret_cast<const f16x8*>(a.sk_w16 + t * 1024 + 512 + lane8);
+      bvA[t] = *reinterpret_cast<const f32x4*>((t < 2 ? a.e1_bias : a.e3_bias) + (t & 1) * 16 + g * 4);
+      kbA[t] = *reinterpret_cast<const f32x4*>(a.sk_bias + t * 16 + g * 4);
+    }
+    load_hw(0);                           // (the other steps' follow the epilogue: register budget)
+    f16x8 sxh[3], sxl[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = g == 0 ? sx0[m][e] : 0.0f, x1 = g == 0 ? sx1[m][e] : 0.0f;
+        const _Float16 h0v = (_Float16)x0, h1v = (_Float16)x1;
+        sxh[m][e] = h0v; sxh[m][4 + e] = h1v;
+        sxl[m][e] = (_Float16)(x0 - (float)h0v); sxl[m][4 + e] = (_Float16)(x1 - (float)h1v);
+      }
+      vmax = absmax4(absmax4(vmax, sx0[m]), sx1[m]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* bb = t < 2 ? a.e1_bias : a.e3_bias;
+      const int tt = t & 1, co = t * 16 + g * 4;
+      const float iv = sload(bb + 32 + tt * 16);
+      const float ki = sload(a.sk_bias + 64 + t * 16);
+      f32x4 z[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        z[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwlA[t], sxh[m], z[m], 0, 0, 0);
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwhA[t], sxl[m], z[m], 0, 0, 0);
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwhA[t], sxh[m], z[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        f32x4 v = fma4(acc[m][t], iv, bvA[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        v += fma4(z[m], ki, kbA[t]);
+        if (!fimg[m]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        vmax = absmax4(vmax, v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        _Float16* d = F + foff[m] + co;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 64) = lo;
+      }
+    }
+    asm volatile("" ::: "memory");
+    load_hw(1); load_hw(2); load_hw(3); load_hw(4);
+  }
+#else
     load_hw(0); load_hw(1); load_hw(2);   // (the last two steps' follow the epilogue: register budget)
     // bias + ReLU, + skip branch (nets/SqueezeSegV2.py:293,319), zero outside the image, split -> F.
     // The skip branch (1x1 conv of the 8-channel input) runs on the matrix cores too: K = 8 is one quarter
@@ -1535,6 +1594,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     asm volatile("" ::: "memory");
     load_hw(3); load_hw(4);
   }
+#endif
   lds_barrier();
   stamp(5);
 
