@@ -29,7 +29,11 @@ tuning: $(SRCS)
 r4x: $(SRCS)
 	$(HIPCC) $(HIPFLAGS) -DPCLSEG_R4X -o pclsegmentation_amd/libpclseg_r4x.so $(CSRC)/pclseg_api.hip
 
+# any other A/B build: make variant NAME=r4x_noslab EXTRA="-DPCLSEG_R4X_TAIL -DPCLSEG_R4X_CAM -DPCLSEG_R4X_WIDE"
+variant: $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -o pclsegmentation_amd/libpclseg_$(NAME).so $(CSRC)/pclseg_api.hip
+
 clean:
 	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so pclsegmentation_amd/libpclseg_tuning.so pclsegmentation_amd/libpclseg_r4x.so pclsegmentation_amd/libpclseg_base.so
 
-.PHONY: all clean stamps tuning r4x
+.PHONY: all clean stamps tuning r4x variant

@@ -594,7 +594,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
     if (exact) return hipErrorInvalidValue;
     size_t slab = (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float);   // rows padded by 4 floats
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_SLAB
     if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (size_t)8 * op.mtw * 16 * (2 * 16 + 4) * sizeof(float);   // two passes (conv_kernel NPASS)
 #endif
     lds = std::max(lds, slab);
@@ -617,7 +617,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     static const int gm = tune_env("PCLSEG_GROUP_MAJOR", -1);
     a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
   }
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_WIDE
   // Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): the software-pipelined GEMM kernel
   if (!exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.ck16 == 64 && op.cin_t % 64 == 0 && op.cin_t >= 128 &&
       op.sub[0].nctp % 8 == 0 && op.sub[0].cout == op.sub[0].nctp * 16 && !a.in_s16 && !a.res1 && !a.res2 && !a.skx && w16) {
@@ -1567,7 +1567,13 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
         lds = (lds_bytes_f16(op, op.ck16) + 15) & ~(int64_t)15;
         if (op.sk_in >= 0) lds += (int64_t)9 * g.tensors[op.out].C * 4;
         if (op.up_fused) lds = ((lds + 15) & ~(int64_t)15) + (int64_t)t.PH * (t.PW / 2 + 1) * (2 * op.cin_t + kPadF16) * 2;
-        if (op.fsq_fused) lds = std::max<int64_t>(lds, (int64_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * 4);
+        if (op.fsq_fused) {
+          int64_t slab = (int64_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * 4;
+#ifdef PCLSEG_R4X_SLAB
+          if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (int64_t)8 * op.mtw * 16 * (2 * 16 + 4) * 4;
+#endif
+          lds = std::max<int64_t>(lds, slab);
+        }
         int ny = 0;
         for (int i = 0; i < op.nsub; ++i) ny += op.sub[i].nctp / (op.ntw * op.wn);
         if (op.pair) ny = op.sub[1].nctp / (op.ntw * op.wn);

@@ -29,6 +29,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Round-4 kernel variants that have not yet been verified on an MI355X: -DPCLSEG_R4X (make r4x) switches all of them on,
+// each one also has its own switch for per-component A/B builds (make r4x EXTRA=-DPCLSEG_R4X_TAIL ... without R4X)
+#ifdef PCLSEG_R4X
+#define PCLSEG_R4X_TAIL 1   // fire_head_kernel: batched up-convolution, prefetched epilogue operands, pipelined conv14 sweep
+#define PCLSEG_R4X_CAM 1    // cam_kernel SQ: fused-squeeze fragments requested one gate pass ahead
+#define PCLSEG_R4X_SLAB 1   // conv_kernel FSQ: fire8/9's partial-sum slab in two passes (70 KB instead of 136 KB)
+#define PCLSEG_R4X_WIDE 1   // conv1x1_wide_kernel for Darknet's wide 1x1 layers
+#endif
+
 namespace pclseg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1000,7 +1009,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
         // Slab rows are padded by 4 floats: with Q a multiple of 16 the 8 consecutive pixels one
         // ds_write_b128 lane group covers would otherwise all start in the same bank (rows 64..256 B
         // apart: an 8- to 16-way conflict that made this phase 29 % of the block).
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_SLAB
         constexpr int Q = FSQ * 16, PXW = MTW * 16;
         // (round 4, -DPCLSEG_R4X) the 136 KB slab of fire8/9 goes through LDS in TWO passes of half the squeeze
         // tiles: 70 KB per block, so that a block of another lane's memory-bound kernel can share the CU
@@ -1324,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   // output column w = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1); U column pc
   // is image column w0 - 2 + pc (w0 - 2 is even, so pc has the parity of w)
   {
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_TAIL
     constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16, NU = (UNITS + 1) / 2, NB = 2;
     static_assert(NU % NB == 0, "units per wave in batches of NB");
     // (the wave's NU units in batches of NB: the batch's fragment reads, then its NB independent 3-MFMA chains,
@@ -1482,7 +1491,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     }
     stamp(4);
     asm volatile("" ::: "memory");
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_TAIL
     // (round 4) the epilogue's own operands — the skip branch's fragments and the two bias quads of each cout tile —
     // are requested HERE, together, into the registers the expand fragments have just left; they were fetched inside
     // the per-tile loop right in front of their use: four L2 round trips in a row per block
@@ -1611,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
 #pragma unroll
       for (int t = 0; t < NCT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fbase = p * kFhCSF + g * 8;
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_TAIL
     // Software-pipelined over the (K-step, row) groups: the two fragment reads of group k + 1 are issued BEFORE the
     // six MFMAs of group k and land while those run (hipcc, left alone, emitted `2 reads, wait, 6 MFMAs` per
     // group: ~100 cycles of LDS latency in front of every 96 cycles of matrix work, 36 times per wave).  A
@@ -1700,7 +1709,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
 
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_WIDE
 // ---- Wide 1x1 convolutions (Darknet's BasicBlock / decoder-block conv1: 128-1024 -> 64-1024 channels), split-f16.
 // Reference: nets/Darknet.py:34-43 (conv1 1x1 + bn1 + LeakyReLU of BasicBlock).
 // conv_kernel runs them as `stage a 64-channel chunk -> barrier -> 2 K-steps -> barrier`: a chunk's matrix work is
@@ -1886,7 +1895,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wide_kernel(const ConvArgs a) 
   }
   if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
-#endif  // PCLSEG_R4X
+#endif  // PCLSEG_R4X_WIDE
 
 // ---- 1x1 convolutions without LDS (split-f16 mode).
 // A 1x1 conv has no halo, so staging its input through LDS only buys the hi/lo split and costs two
@@ -2395,7 +2404,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
 #pragma unroll
   for (int nn = 0; nn < (SQ > 0 ? SQ : 1); ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float vmax = 0.f;
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_CAM
   // fused squeeze: a chunk's weight fragments are requested one gate pass AHEAD of their MFMAs (they were fetched
   // right in front of them: NCH * CK/32 exposed L2 round trips per block, in a kernel whose blocks are short
   // chains of dependent phases; all chunks at once costs 16 more registers than the 128 this kernel may use)
@@ -2461,7 +2470,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
         for (int t = 0; t < CK / 32; ++t) {
           const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + t * 32);
           const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + t * 32 + CK);
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_CAM
 #pragma unroll
           for (int nn = 0; nn < SQ; ++nn) {
             const f16x8 wh = swh[t][nn], wl = swl[t][nn];
@@ -2478,7 +2487,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
           }
         }
       }
-#ifdef PCLSEG_R4X
+#ifdef PCLSEG_R4X_CAM
       if (chunk + 1 < NCH) {
         asm volatile("" ::: "memory");   // (the next chunk's fragments: requested AFTER this chunk's MFMAs have read theirs)
         load_sqw(chunk + 1);
