@@ -610,7 +610,10 @@ def main():
       y["model"]._drop_engines()
       del y
     # ---- BASELINE configs[0] in the reference's loop shape, on the GPU
-    c1 = c1_gpu_leg(P, E, synthetic_weights, dev_index)
+    try:      # (a leg added this round: whatever goes wrong in it must not cost the driver its bench line)
+      c1 = c1_gpu_leg(P, E, synthetic_weights, dev_index)
+    except Exception as e:   # noqa: BLE001
+      c1 = {"error": "%s: %s" % (type(e).__name__, e)}
     if c1:
       out["c1_gpu"] = c1
     # ---- parity evidence of this very build, outside every timed region

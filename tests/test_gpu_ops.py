@@ -15,6 +15,8 @@ import pytest
 from oracle import np_oracle as O
 from pclsegmentation_amd import engine as E
 
+from conftest import unverified_on_gpu
+
 pytestmark = pytest.mark.gpu
 
 
@@ -71,8 +73,10 @@ CONV_CASES = [
   (1, 8, 16, 48, 192, 3, 1, "relu", True, True, True),       # partial last chunk (48 = 32+16)
   (1, 8, 16, 256, 512, 3, 1, "leaky", False, True, True),    # darknet-sized
   (1, 3, 130, 4, 20, 1, 1, "none", True, False, False),      # cout 20 -> padded tile
-  # Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): flat pixels, 128-pixel tiles (ragged last tile),
-  # 2 .. 16 channel chunks, one and two cout groups
+]
+# Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): flat pixels, 128-pixel tiles (ragged last tile),
+# 2 .. 16 channel chunks, one to four cout groups — the shapes conv1x1_wide_kernel (make r4x) takes over
+WIDE_1X1_CASES = [
   (1, 8, 40, 256, 128, 1, 1, "leaky", False, True, False),   # enc3-like: 8 cout tiles, 320 px = 2.5 tiles
   (2, 4, 33, 128, 256, 1, 1, "leaky", False, True, False),   # dec3-like: 2 chunks, 16 cout tiles, 264 px
   (1, 4, 96, 1024, 512, 1, 1, "leaky", False, True, False),  # enc5-like: 16 chunks, 2 cout groups, 3 tiles
@@ -86,6 +90,17 @@ MATHS = ["f16x3", "f32"]
 @pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_conv2d(cuda, case, math):
+  _conv2d_case(cuda, case, math)
+
+
+@unverified_on_gpu
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("case", WIDE_1X1_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_wide_1x1(cuda, case, math):
+  _conv2d_case(cuda, case, math)
+
+
+def _conv2d_case(cuda, case, math):
   import torch
   n, h, w, cin, cout, k, s, act, use_bias, use_bn, use_res = case
   rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
