@@ -329,6 +329,8 @@ def attach_traffic(roof, workload, scans_per_s_dev, info):
   roof["traffic"] = int(w["hbm_bytes_per_scan"])
   roof["traffic_unit"] = ("HBM-side bytes per scan, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE), "
                           "%s, csrc sha %s = pclseg_build_sha() of the binary that ran" % (name, t["csrc_sha"]))
+  if t.get("carried_over"):
+    roof["traffic_unit"] += "; measured on csrc sha %s — %s" % (t.get("measured_on_csrc_sha"), t["carried_over"])
   roof["physical"] = {
     "hbm_frac": round(w["hbm_bytes_per_scan"] * scans_per_s_dev / (HBM_PEAK_GBS * 1e9), 4),
     "mfma_frac": round(3 * 2 * info["alg_macs_per_scan"] * scans_per_s_dev / (F16_MFMA_PEAK_TF * 1e12), 4),
