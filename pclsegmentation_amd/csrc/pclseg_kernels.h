@@ -2491,7 +2491,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
       if (chunk + 1 < NCH) {
         asm volatile("" ::: "memory");   // (the next chunk's fragments: requested AFTER this chunk's MFMAs have read theirs)
         load_sqw(chunk + 1);
-        __syncthreads();
+        lds_barrier();                   // (orders LDS only: a __syncthreads() would drain vmcnt and wait for the request right here)
       }
 #else
       if (chunk + 1 < NCH) __syncthreads();
