@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 R4X=$GRAFT_REPO_ROOT/pclsegmentation_amd/libpclseg_r4x.so
 timeout 1200 python -m pytest tests/test_preproc_golden.py tests/test_gpu_ops.py tests/test_c_abi.py tests/test_gpu_models.py -m gpu -x -q -k "preproc or golden or fused or full_size_kitti or c1_reference or normalize or head or abi or range or host_boundary" > gpurun_out/r04_run2_tests.log 2>&1; tail -4 gpurun_out/r04_run2_tests.log
 PCLSEG_LIB=$R4X timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -m gpu -x -q -k "conv2d or golden or fused or full_size or c1_reference or intermediate or micro_batch or strides" > gpurun_out/r04_run2_tests_r4x.log 2>&1; tail -4 gpurun_out/r04_run2_tests_r4x.log
+timeout 900 python scripts/ab_bitwise.py $GRAFT_REPO_ROOT/pclsegmentation_amd/libpclseg.so $R4X > gpurun_out/r04_run2_bitwise.log 2>&1; tail -12 gpurun_out/r04_run2_bitwise.log
 NOSLAB=$GRAFT_REPO_ROOT/pclsegmentation_amd/libpclseg_r4x_noslab.so
 SKIP_TESTS=1 timeout 1200 bash scripts/quick.sh "" "PCLSEG_LIB=$R4X" "PCLSEG_LIB=$NOSLAB" "" "PCLSEG_LIB=$R4X" "PCLSEG_LIB=$NOSLAB" > gpurun_out/r04_run2_ab.log 2>&1; cat gpurun_out/r04_run2_ab.log | tail -44
 timeout 300 bash scripts/stamps.sh ssv2_64x2048 fire13 > gpurun_out/r04_run2_stamps.log 2>&1
