@@ -36,6 +36,7 @@
 #define PCLSEG_R4X_CAM 1    // cam_kernel SQ: fused-squeeze fragments requested one gate pass ahead
 #define PCLSEG_R4X_SLAB 1   // conv_kernel FSQ: fire8/9's partial-sum slab in two passes (70 KB instead of 136 KB)
 #define PCLSEG_R4X_WIDE 1   // conv1x1_wide_kernel for Darknet's wide 1x1 layers
+#define PCLSEG_R4X_KPIPE 1  // conv_kernel GEOM 1, fire8/9's 64-pixel merged pairs: fragment reads one K-step ahead of the MFMAs
 #endif
 
 namespace pclseg {
@@ -803,6 +804,69 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
             __builtin_amdgcn_sched_barrier(0);
           }
         };
+#ifdef PCLSEG_R4X_KPIPE
+        // (round 4) the merged pairs' 64-pixel blocks (fire8/9: one block per CU, two waves per SIMD, 186
+        // registers): hipcc emits a K-step as `4 reads, wait, 12 NTW MFMAs` — every step starts with an LDS round
+        // trip.  Here the 8 fragment reads of step st + 1 are issued BEFORE the MFMAs of step st (two register
+        // sets, scheduling-group barriers keep the order), as in conv1x1_wide_kernel.
+        // (NTW >= 2 only: fire10's kernel — one cout tile per wave — sits at 120 registers with two blocks per CU,
+        // the second fragment set would cost it that: 154)
+        if constexpr (MTW == 4 && NTW >= 2 && !OCC128) {
+          f16x8 xh[2][4], xl[2][4];
+          auto rd = [&](const int off, const int set) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              xh[set][m] = *reinterpret_cast<const f16x8*>(xb + off + m * (kPW * kCS));
+              xl[set][m] = *reinterpret_cast<const f16x8*>(xb + off + m * (kPW * kCS) + kPlane);
+            }
+          };
+          auto mm = [&](const int set, const int slot) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+              for (int nn = 0; nn < NTW; ++nn) {
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot][nn], xh[set][m], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][nn], xl[set][m], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][nn], xh[set][m], acc[m][nn], 0, 0, 0);
+              }
+          };
+          const bool is3 = !PAIR || K.nkh == 3;
+          const int nst = is3 ? 18 : 2;
+          const _Float16* wb = K.w16 + ((size_t)(chunk * nst) * K.nctp + ct0) * 1024;   // scalar
+          auto load_w = [&](const int st, const int slot) {
+            const _Float16* wp = wb + (size_t)st * wstep;
+#pragma unroll
+            for (int nn = 0; nn < NTW; ++nn) {
+              wh[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + lane8);
+              wl[slot][nn] = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512 + lane8);
+            }
+          };
+          load_w(0, 0);
+          load_w(1, 1);
+          if (is3) {
+            rd(0, 0);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+              if (st + 1 < 18) {
+                const int tap = (st + 1) >> 1, ti = tap / 3, tj = tap - 3 * ti;
+                rd((ti * kPW + tj) * kCS + ((st + 1) & 1) * 32, (st + 1) & 1);
+              }
+              mm(st & 1, st & 1);
+              if (st + 1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 12 * NTW, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (st + 2 < 18) load_w(st + 2, st & 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {            // 1x1 half of a merged pair: the centre tap, 2 K-steps
+            rd((1 * kPW + 1) * kCS, 0);
+            rd((1 * kPW + 1) * kCS + 32, 1);
+            mm(0, 0);
+            mm(1, 1);
+          }
+          return;
+        }
+#endif
         if (!PAIR || K.nkh == 3) {   // 3x3: 18 K-steps, tap s / 2 (single convs are always 3x3 here: host-checked)
           constexpr int kSteps = 18;
           const _Float16* wb = K.w16 + ((size_t)(chunk * kSteps) * K.nctp + ct0) * 1024;   // scalar
