@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,15 +38,20 @@ constexpr int tune_env(const char*, int dflt) { return dflt; }
 // that rank's plan, and the error that reports it (pclseg_import_packed's plan mismatch) prints the resolved set.
 struct DebugSwitches {
   static std::vector<std::pair<std::string, int>>& seen() { static std::vector<std::pair<std::string, int>> v; return v; }
-  static std::string text() {
+  static std::string text();
+};
+inline std::mutex& debug_env_mutex();
+inline std::string DebugSwitches::text() {
+    std::lock_guard<std::mutex> lock(debug_env_mutex());
     std::string t;
     for (const auto& kv : seen()) t += (t.empty() ? "" : " ") + kv.first + "=" + std::to_string(kv.second);
     return t.empty() ? "none read yet" : t;
-  }
-};
+}
+inline std::mutex& debug_env_mutex() { static std::mutex m; return m; }
 inline int debug_env(const char* name, int dflt) {
   const char* v = getenv(name);
   const int r = v ? atoi(v) : dflt;
+  std::lock_guard<std::mutex> lock(debug_env_mutex());   // (handles may be created from several threads at once)
   for (auto& kv : DebugSwitches::seen()) if (kv.first == name) { kv.second = r; return r; }
   DebugSwitches::seen().emplace_back(name, r);
   return r;
