@@ -393,6 +393,16 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
+#ifdef PCLSEG_R4X_GEOM2
+  // fire4 (32 -> 128 + 128 -> 32, 4 x 16-pixel tiles, WN = 8): conv_kernel GEOM 2
+  if (op.mtw == 4 && op.ntw == 1 && op.wn == 8 && a.fsq_q == 32 && epi == 0 && op.cin_t == 32 && a.in_s16 && a.PW == 18 && a.PH == 6 &&
+      op.ck16 >= 32 && !op.up_fused) {
+    auto kfn = conv_kernel<4, 1, 8, false, true, 0, true, 8, 2, 0, 0, false, 2>;
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds)) return e;
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+  }
+#endif
 #define PCLSEG_X(M_, N_, W_, Q_, E_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16 && epi == E_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_>; \
@@ -420,6 +430,16 @@ hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStrea
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
+#ifdef PCLSEG_R4X_GEOM2
+  // fire11 (32-channel up-convolved patch, 8 x 16-pixel tiles, WN = 4): conv_kernel GEOM 2
+  if (op.mtw == 4 && op.ntw == 1 && op.wn == 4 && op.nw == 8 && nq == 1 && epi == 1 && op.cin_t == 32 && a.PW == 18 && a.PH == 10 &&
+      op.ck16 >= 32) {   // (one chunk: 40 halfs per staged pixel and plane)
+    auto kfn = conv_kernel<4, 1, 4, false, true, 1, true, 8, 1, 2, 0, false, 2>;
+    if (hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(kfn), lds)) return e;
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+  }
+#endif
 #define PCLSEG_X(M_, N_, W_, Q_, E_, U_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == 8 && nq == Q_ && epi == E_ && op.cin_t == 16 * U_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_, U_>; \

@@ -37,6 +37,7 @@
 #define PCLSEG_R4X_SLAB 1   // conv_kernel FSQ: fire8/9's partial-sum slab in two passes (70 KB instead of 136 KB)
 #define PCLSEG_R4X_WIDE 1   // conv1x1_wide_kernel for Darknet's wide 1x1 layers
 #define PCLSEG_R4X_KPIPE 1  // conv_kernel GEOM 1, fire8/9's 64-pixel merged pairs: fragment reads one K-step ahead of the MFMAs
+#define PCLSEG_R4X_GEOM2 1  // conv_kernel GEOM 2: compile-time geometry K loop for the 32-channel merged pairs (fire4, fire11)
 #endif
 
 namespace pclseg {
@@ -773,6 +774,57 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
     };
 
     auto kloop = [&](const ConvSub& K, const int chunk, const int ck8, const _Float16* const sm) {   // (sm: the LDS buffer to read)
+#ifdef PCLSEG_R4X_GEOM2
+      // GEOM = 2 (round 4): the same compile-time geometry for the merged pairs with a 32-channel patch — fire4 (64-pixel
+      // tiles, WN = 8) and fire11 (128-pixel tiles, WN = 4: wave (wm, wn) owns tile rows 4 wm .. 4 wm + 3) — whose K loop is
+      // 9 K-steps of 12 MFMAs: one step = one tap (lane group g = channels 8 g ..), every fragment address one per-lane
+      // base plus an immediate.  Their generic loop spends 13 vector instructions of address arithmetic per step and
+      // waits after every second read.
+      if constexpr (GEOM == 2) {
+        static_assert(MTW == 4 && NTW == 1 && NW == 8 && PAIR, "GEOM 2: 4 x 16-pixel row segments per wave, one cout tile");
+        constexpr int kPW = 18, kCS = 40, kRows = (NW / WN) * MTW, kPlane = (kRows + 2) * kPW * kCS;   // (host-checked against a.PW / CSh / plane)
+        const unsigned wstep = (unsigned)K.nctp * 1024u;
+        const unsigned lane8 = (unsigned)lane * 8u;
+        const _Float16* xb = sm + ((wm * MTW) * kPW + p) * kCS + g * 8;   // segment m = tile row wm * 4 + m
+        const bool is3 = K.nkh == 3;
+        const int nst = is3 ? 9 : 1;
+        const _Float16* wb = K.w16 + ((size_t)(chunk * nst) * K.nctp + ct0) * 1024;   // scalar
+        f16x8 wh[2], wl[2];
+        auto load_w = [&](const int st, const int slot) {
+          wh[slot] = *reinterpret_cast<const f16x8*>(wb + (size_t)st * wstep + lane8);
+          wl[slot] = *reinterpret_cast<const f16x8*>(wb + (size_t)st * wstep + 512 + lane8);
+        };
+        auto gstep = [&](const int off, const int slot) {
+          f16x8 xh[4], xl[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            xh[m] = *reinterpret_cast<const f16x8*>(xb + off + m * (kPW * kCS));
+            xl[m] = *reinterpret_cast<const f16x8*>(xb + off + m * (kPW * kCS) + kPlane);
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot], xh[m], acc[m][0], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot], xl[m], acc[m][0], 0, 0, 0);
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot], xh[m], acc[m][0], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        load_w(0, 0);
+        if (is3) {
+          load_w(1, 1);
+#pragma unroll
+          for (int st = 0; st < 9; ++st) {
+            const int ti = st / 3, tj = st - 3 * ti;
+            gstep((ti * kPW + tj) * kCS, st & 1);
+            if (st + 2 < 9) load_w(st + 2, st & 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          gstep((1 * kPW + 1) * kCS, 0);
+        }
+        return;
+      }
+#endif
       if constexpr (GEOM == 1) {
         static_assert((MTW == 8 || MTW == 4) && WN == 8 && NW == 8, "GEOM 1: MTW x 16-pixel tiles (one segment per tile row) of the 8-wave blocks");
         constexpr int kPW = 18, kCS = 72, kPlane = (MTW + 2) * 18 * 72;   // (host-checked against a.PW / CSh / plane)
