@@ -4,36 +4,38 @@ ARCH  ?= gfx950
 CSRC  := pclsegmentation_amd/csrc
 LIB   := pclsegmentation_amd/libpclseg.so
 SRCS  := $(CSRC)/pclseg_kernels.h $(CSRC)/pclseg_graph.h $(CSRC)/pclseg_api.hip include/pclseg.h
-# sha256 over the sources, in the order bench.py's csrc_sha() reads them, baked into the library
-# (pclseg_build_sha): bench.py compares it with the sources next to it and refuses to quote a PMC
-# traffic figure when the binary that ran was built from something else
-SRC_SHA := $(shell cat $(SRCS) | sha256sum | cut -c1-16)
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function -DPCLSEG_SRC_SHA=\"$(SRC_SHA)\" $(EXTRA)
+# sha256 over the sources (in the order bench.py's csrc_sha() reads them) FOLLOWED BY the build's -D switches, baked into
+# the library (pclseg_build_sha): bench.py compares it with the sources next to it and refuses to quote a PMC traffic
+# figure when the binary that ran was built from something else.  The shipped build has no switches, so its hash is the
+# hash of the sources alone; every stamps / tuning / variant build hashes differently and is never mistaken for it.
+sha = $(shell (cat $(SRCS); printf '%s' '$(strip $(1))') | sha256sum | cut -c1-16)
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -Wall -Wno-unused-function
+# $(call hipbuild,<output>,<-D switches>)
+hipbuild = $(HIPCC) $(HIPFLAGS) $(2) -DPCLSEG_SRC_SHA=\"$(call sha,$(2))\" -o $(1) $(CSRC)/pclseg_api.hip
 
 all: $(LIB)
 
 $(LIB): $(SRCS)
-	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/pclseg_api.hip
+	$(call hipbuild,$@,$(EXTRA))
 
-# debug build with in-kernel phase timestamps (PCLSEG_STAMP=<layer> PCLSEG_LIB=.../libpclseg_stamps.so)
+# debug build with in-kernel phase timestamps (PCLSEG_STAMP=<layer>, loaded through PCLSEG_DEBUG_LIB)
 stamps: $(SRCS)
-	$(HIPCC) $(HIPFLAGS) -DPCLSEG_WITH_STAMPS -o pclsegmentation_amd/libpclseg_stamps.so $(CSRC)/pclseg_api.hip
+	@mkdir -p build
+	$(call hipbuild,build/libpclseg_stamps.so,-DPCLSEG_WITH_STAMPS $(EXTRA))
 
 # A/B build: the experiment switches of DESIGN.md §9/§10 (PCLSEG_GEOM, PCLSEG_DN8, ...) are read from the
-# environment (PCLSEG_LIB=.../libpclseg_tuning.so); the shipped library carries only their defaults
+# environment; the shipped library carries only their defaults
 tuning: $(SRCS)
-	$(HIPCC) $(HIPFLAGS) -DPCLSEG_TUNING -o pclsegmentation_amd/libpclseg_tuning.so $(CSRC)/pclseg_api.hip
+	@mkdir -p build
+	$(call hipbuild,build/libpclseg_tuning.so,-DPCLSEG_TUNING $(EXTRA))
 
-# experiment build of the round: kernel variants that have NOT yet been verified on an MI355X are compiled only
-# with -DPCLSEG_R4X (A/B: PCLSEG_LIB=.../libpclseg_r4x.so); the shipped library carries the verified code paths
-r4x: $(SRCS)
-	$(HIPCC) $(HIPFLAGS) -DPCLSEG_R4X -o pclsegmentation_amd/libpclseg_r4x.so $(CSRC)/pclseg_api.hip
-
-# any other A/B build: make variant NAME=r4x_noslab EXTRA="-DPCLSEG_R4X_TAIL -DPCLSEG_R4X_CAM -DPCLSEG_R4X_WIDE"
+# any other A/B build: make variant NAME=foo EXTRA="-DPCLSEG_..."  ->  build/libpclseg_foo.so
 variant: $(SRCS)
-	$(HIPCC) $(HIPFLAGS) -o pclsegmentation_amd/libpclseg_$(NAME).so $(CSRC)/pclseg_api.hip
+	@mkdir -p build
+	$(call hipbuild,build/libpclseg_$(NAME).so,$(EXTRA))
 
 clean:
-	rm -f $(LIB) pclsegmentation_amd/libpclseg_stamps.so pclsegmentation_amd/libpclseg_tuning.so pclsegmentation_amd/libpclseg_r4x.so pclsegmentation_amd/libpclseg_base.so
+	rm -f $(LIB) pclsegmentation_amd/libpclseg_*.so
+	rm -rf build sim/_build
 
-.PHONY: all clean stamps tuning r4x variant
+.PHONY: all clean stamps tuning variant

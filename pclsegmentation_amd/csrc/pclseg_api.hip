@@ -28,7 +28,10 @@ using namespace pclseg;
 namespace {
 
 thread_local std::string g_last_error;
-thread_local const char* g_static_error = nullptr;   // set when not even the message string could be built (exception barrier)
+// set when not even the message string could be built (exception barrier); it belongs to the handle (or NULL, for
+// the handle-less entry points) whose call failed — pclseg_last_error of any OTHER handle still reads that handle's own text
+thread_local const char* g_static_error = nullptr;
+thread_local const pclseg_handle* g_static_handle = nullptr;
 
 constexpr double kBnEps = 1e-3;  // Keras BatchNormalization default (no epsilon= in nets/*.py)
 
@@ -113,7 +116,7 @@ struct pclseg_handle {
 namespace {
 
 int fail(pclseg_handle* h, int code, const std::string& msg) {
-  g_static_error = nullptr;
+  if (h == g_static_handle) g_static_error = nullptr;
   g_last_error = msg;
   if (h) h->err = msg;
   return code;
@@ -1467,6 +1470,7 @@ int on_exception(const pclseg_handle* ch) noexcept {
     return fail(h, code, what);
   } catch (...) {
     g_static_error = code == PCLSEG_ERR_OOM ? "out of host memory (std::bad_alloc)" : "internal error (C++ exception)";
+    g_static_handle = ch;
     return code;
   }
 }
@@ -1491,7 +1495,7 @@ int pclseg_version(void) { return PCLSEG_VERSION; }
 const char* pclseg_build_sha(void) { return PCLSEG_SRC_SHA; }
 
 const char* pclseg_last_error(const pclseg_handle* h) try {
-  if (g_static_error) return g_static_error;
+  if (g_static_error && h == g_static_handle) return g_static_error;
   if (h) return h->err.c_str();
   return g_last_error.c_str();
 } catch (...) { return "pclseg_last_error: internal error"; }

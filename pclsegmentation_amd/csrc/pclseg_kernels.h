@@ -129,8 +129,11 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 // 2-3.5 us (10-12 %) off the FIRE expand pairs that only write (fire2-fire7), and ADDS 6-8 us to the
 // ones that also read a skip tensor (fire10-fire13) — hence a per-launch switch (ConvArgs::wt).
 __device__ __forceinline__ void store_quad(float* dst, const f32x4 v, const bool write_through) {
+#ifndef PCLSEG_SIM
   if (write_through) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
-  else *reinterpret_cast<f32x4*>(dst) = v;
+  else
+#endif
+    *reinterpret_cast<f32x4*>(dst) = v;
 }
 
 // Accumulator -> pre-activation value.  Split-f16 weights are packed with a power-of-two scale 2^k per
@@ -139,7 +142,11 @@ __device__ __forceinline__ void store_quad(float* dst, const f32x4 v, const bool
 // rounds).  The tile index is wave-uniform, so 2^-k comes through the scalar cache into an SGPR
 // (constant address space: the parameter blob is never written while a kernel runs) — no vector
 // register, no vector-memory instruction.
+#ifndef PCLSEG_SIM
 typedef __attribute__((address_space(4))) const float* const_f32_ptr;
+#else
+typedef const float* const_f32_ptr;
+#endif
 __device__ __forceinline__ float sload(const float* p) { return *(const_f32_ptr)(p); }
 __device__ __forceinline__ f32x4 fma4(const f32x4 a, const float s, const f32x4 b) {
   f32x4 r;
@@ -150,7 +157,11 @@ __device__ __forceinline__ f32x4 fma4(const f32x4 a, const float s, const f32x4 
 
 // Workgroup barrier that leaves this wave's global loads in flight: __syncthreads() drains vmcnt too, which
 // would turn every prefetch issued before it into a stall at it.  LDS traffic is ordered by lgkmcnt.
+#ifndef PCLSEG_SIM
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else   // (functional simulator, sim/: tests only)
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#endif
 
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
@@ -401,7 +412,9 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
     // opaque copies of the lane coordinates: everything the epilogue derives from them is computed
     // HERE, not hoisted above the K loop where it would cost registers for its whole duration
     int p = lane & 15, g = lane >> 4;
+#ifndef PCLSEG_SIM
     asm volatile("" : "+v"(p), "+v"(g));
+#endif
     f32x4 bv[NTW];
     float iv[F16X3 ? NTW : 1];   // (split-f16) inverse weight scale of each cout tile, scalar
 #pragma unroll

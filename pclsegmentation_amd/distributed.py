@@ -96,9 +96,12 @@ def broadcast_engine(model, height, width, flags=0, src=0, device=None):
   RCCL/xGMI device to device — and the other ranks import it (pclseg_import_packed: a device copy).
   Darknet-53: one 216 MB collective instead of eight host-side fold + repack passes of 53 M parameters.
 
-  A 16-byte status broadcast goes first: if rank ``src`` cannot build its engine (no weights bound,
-  pclseg_finalize refusing non-finite folded weights, out of memory) EVERY rank raises, instead of the
-  other ranks waiting in the blob's collective until the RCCL / gloo timeout.
+  Two small collectives guard the big one, so that no rank is ever left waiting in the blob's collective
+  until the RCCL / gloo timeout: a 16-byte status broadcast (rank ``src`` could not build its engine: no
+  weights bound, pclseg_finalize refusing non-finite folded weights, out of memory), then — after every
+  OTHER rank has created its receiving engine and compared its packed size — a MIN all-reduce of
+  ``rank if failed else world`` (out of memory with several ranks on one GPU, different library builds or
+  fusion switches between ranks).  If either reports a failure EVERY rank raises, naming the failing rank.
 
   With PCLSEG_FORCE_COLLECTIVES=1 a one-rank group runs the same sequence and returns the engine that
   IMPORTED the broadcast blob (the source engine is dropped), so a single-GPU box executes the transport."""
@@ -130,11 +133,25 @@ def broadcast_engine(model, height, width, flags=0, src=0, device=None):
     if err is not None:
       raise err
     raise RuntimeError("broadcast_engine: rank %d could not build the engine (see its log)" % src)
+  dst = None
+  world, rank = dist.get_world_size(), dist.get_rank()
   if not is_src or loopback:
-    dst = _engine.Engine(model.engine_desc(height, width, flags))
-    if dst.packed_size() != nbytes:
-      raise RuntimeError("broadcast_engine: rank %d packs %d bytes, this rank's plan needs %d "
-                         "(different library builds or fusion switches between ranks?)" % (src, nbytes, dst.packed_size()))
+    try:
+      dst = _engine.Engine(model.engine_desc(height, width, flags))
+      if dst.packed_size() != nbytes:
+        raise RuntimeError("broadcast_engine: rank %d packs %d bytes, this rank's plan needs %d "
+                           "(different library builds or fusion switches between ranks?)" % (src, nbytes, dst.packed_size()))
+    except Exception as e:      # every rank learns of it below, then it is re-raised here
+      err = e
+  first_bad = torch.full((1,), world if err is None else rank, dtype=torch.int64, device=device)
+  dist.all_reduce(first_bad, op=dist.ReduceOp.MIN)
+  first_bad = int(first_bad.item())
+  if first_bad < world:
+    if dst is not None:
+      dst.close()
+    if err is not None:
+      raise err
+    raise RuntimeError("broadcast_engine: rank %d could not create its receiving engine (see its log)" % first_bad)
   blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
   if is_src:
     eng.export_packed(blob)

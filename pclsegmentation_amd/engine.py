@@ -13,7 +13,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PCLSEG_LIB") or os.path.join(_HERE, "libpclseg.so")   # override: A/B of two builds
+LIB_PATH = os.path.join(_HERE, "libpclseg.so")
+# A/B of two builds (scripts/, tests/simlib.py): another binary is loaded ONLY when the debug switch is set as well — a
+# stray PCLSEG_LIB in a production environment changes nothing — and the swap is announced on stderr at load.
+DEBUG_LIB = bool(os.environ.get("PCLSEG_LIB")) and os.environ.get("PCLSEG_DEBUG") == "1"
+if DEBUG_LIB:
+  LIB_PATH = os.environ["PCLSEG_LIB"]
 
 OK = 0
 ERR_BAD_ARG, ERR_BAD_SHAPE, ERR_MISSING_WEIGHT, ERR_HIP, ERR_OOM, ERR_STATE, ERR_RANGE, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
@@ -80,7 +85,9 @@ def load_library():
       "libpclseg.so not found at %s — build it with `make` (or __graft_entry__.build()); "
       "this engine has no CPU fallback" % LIB_PATH)
   lib = ctypes.CDLL(LIB_PATH)
-  if "PCLSEG_LIB" in os.environ:   # A/B against an older build: entry points it lacks fail at the call, not at load
+  if DEBUG_LIB:   # A/B against an older build: entry points it lacks fail at the call, not at load
+    import sys
+    sys.stderr.write("pclseg: PCLSEG_DEBUG=1, loading %s instead of the shipped library\n" % LIB_PATH)
     class _Missing:
       def __init__(self, name):
         self.name, self.argtypes, self.restype = name, None, None
@@ -212,6 +219,30 @@ def plan_op_resources(desc):
   return [(f[0],) + tuple(int(x) for x in f[1:5]) for f in (l.split("\t") for l in buf.value.decode().splitlines())]
 
 
+# ---- where tensors live.  PyTorch is only the device-memory container of this package; these three functions are
+# the one place that says how a device, its current stream, "is on the device" and "is page-locked" are spelled in torch.
+def torch_device(index=0):
+  """torch.device of HIP device ``index`` (tensors handed to MEM_DEVICE calls live there)."""
+  import torch
+  return torch.device("cuda", int(index))
+
+
+def stream_handle(device):
+  """Raw hipStream_t of torch's current stream on ``device`` (what pclseg_set_stream takes)."""
+  import torch
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device(x):
+  """True for a tensor in device memory; NumPy arrays and CPU tensors are host memory."""
+  return bool(getattr(x, "is_cuda", False))
+
+
+def is_pinned(x):
+  """True for a page-locked host tensor (MEM_HOST_ASYNC needs one)."""
+  return bool(x.is_pinned())
+
+
 def _host_f32(a):
   return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
@@ -256,11 +287,11 @@ def _checked(x, dtype, count, what, mem=None):
       raise ValueError("pclseg: %s must be contiguous" % what)
     if x.numel() < count:
       raise ValueError("pclseg: %s holds %d elements, the call needs %d" % (what, x.numel(), count))
-    if mem == MEM_HOST_ASYNC and not x.is_cuda and not x.is_pinned():
+    if mem == MEM_HOST_ASYNC and not on_device(x) and not is_pinned(x):
       raise ValueError("pclseg: %s must be page-locked (pin_memory) for MEM_HOST_ASYNC" % what)
-    if mem is not None and x.is_cuda != (mem == MEM_DEVICE):
+    if mem is not None and on_device(x) != (mem == MEM_DEVICE):
       raise ValueError("pclseg: %s lives on %s but the call was made with mem=%s" % (
-        what, "the device" if x.is_cuda else "the host", "MEM_DEVICE" if mem == MEM_DEVICE else "MEM_HOST[_ASYNC]"))
+        what, "the device" if on_device(x) else "the host", "MEM_DEVICE" if mem == MEM_DEVICE else "MEM_HOST[_ASYNC]"))
     return x
   return x   # raw integer address: the caller vouches for it
 
@@ -328,7 +359,7 @@ class Engine:
       return _ptr(buf), buf.size, MEM_HOST
     if str(buf.dtype) != "torch.uint8" or not buf.is_contiguous():
       raise ValueError("pclseg: packed blob must be a contiguous uint8 tensor")
-    return _ptr(buf), buf.numel(), (MEM_DEVICE if buf.is_cuda else MEM_HOST)
+    return _ptr(buf), buf.numel(), (MEM_DEVICE if on_device(buf) else MEM_HOST)
 
   def export_packed(self, buf):
     p, n, mem = self._blob(buf)

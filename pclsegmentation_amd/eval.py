@@ -46,7 +46,7 @@ class MeanIoU:
     import torch
     self.num_classes = int(num_classes)
     self.name = name
-    self._dev = torch.device("cuda", device)
+    self._dev = _engine.torch_device(device)
     self._cm = torch.zeros((self.num_classes, self.num_classes), dtype=torch.int64, device=self._dev)
     self._seen = 0
 
@@ -66,7 +66,7 @@ class MeanIoU:
       raise ValueError("label and predictions differ in size: %d vs %d" % (lab.numel(), prd.numel()))
     self._seen += lab.numel()
     _engine.op_confusion_matrix(lab, prd, lab.numel(), self.num_classes, self._cm,
-                                torch.cuda.current_stream(self._dev).cuda_stream)
+                                _engine.stream_handle(self._dev))
 
   @property
   def total_cm(self):
@@ -110,7 +110,7 @@ def evaluation(arg):
   miou_tracker = MeanIoU(num_classes=config.NUM_CLASS, name="MeanIoU")
   print("Performing Evaluation")
   import torch
-  dev = torch.device("cuda", model.device)
+  dev = _engine.torch_device(model.device)
   for b0 in range(0, len(files), arg.batch):
     samples = torch.from_numpy(np.stack([np.load(f).astype(np.float32) for f in files[b0:b0 + arg.batch]])).to(dev)
     predictions, mask = model.predict_raw(samples[..., :5], return_mask=True)       # device tensors

@@ -120,7 +120,7 @@ class PCLSegmentationNetwork:
     if training:
       raise NotImplementedError("this engine implements the inference path only")
     lidar_input, lidar_mask = inputs[0], inputs[1]
-    if _is_torch(lidar_input):
+    if _is_torch(lidar_input) and _engine.on_device(lidar_input):     # (a CPU tensor takes the host path below)
       return self._call_device(lidar_input, lidar_mask, return_probabilities)
     lidar = np.ascontiguousarray(np.asarray(lidar_input), dtype=np.float32)  # Keras casts to f32
     msk = np.asarray(lidar_mask)
@@ -147,7 +147,7 @@ class PCLSegmentationNetwork:
     if c != self.NUM_FEATURES:
       raise ValueError("lidar must have shape [N,H,W,%d]" % self.NUM_FEATURES)
     eng = self.engine(h, w)
-    eng.set_stream(torch.cuda.current_stream(lidar.device).cuda_stream)
+    eng.set_stream(_engine.stream_handle(lidar.device))
     preds = torch.empty((n, h, w), dtype=torch.int32, device=lidar.device)
     probs = (torch.empty((n, h, w, self.NUM_CLASS), dtype=torch.float32, device=lidar.device)
              if return_probabilities else None)
@@ -165,12 +165,12 @@ class PCLSegmentationNetwork:
   def predict_raw(self, scans, return_mask=False):
     """Raw scans [N,H,W,5] (x,y,z,intensity,depth) -> predictions, with the reference's
     caller-side pre-processing (inference.py:50-62) done on the device."""
-    if _is_torch(scans):
+    if _is_torch(scans) and _engine.on_device(scans):
       import torch
       scans = scans.float().contiguous()
       n, h, w, _ = scans.shape
       eng = self.engine(h, w)
-      eng.set_stream(torch.cuda.current_stream(scans.device).cuda_stream)
+      eng.set_stream(_engine.stream_handle(scans.device))
       preds = torch.empty((n, h, w), dtype=torch.int32, device=scans.device)
       mask = torch.empty((n, h, w), dtype=torch.uint8, device=scans.device) if return_mask else None
       eng.forward_raw(scans, n, preds, None, None, mask, mem=_engine.MEM_DEVICE)

@@ -29,7 +29,7 @@ class LaserScan:
     self.proj_H, self.proj_W = int(H), int(W)
     self.proj_fov_up, self.proj_fov_down = fov_up, fov_down
     self.use_ring_projection = bool(use_ring_projection)
-    self._dev = torch.device("cuda", device)
+    self._dev = _engine.torch_device(device)
     self._scratch = torch.empty(self.proj_H * self.proj_W, dtype=torch.int64, device=self._dev)
     self.image = None
     self._idx = None
@@ -83,7 +83,7 @@ class LaserScan:
                                   fov_down=self.proj_fov_down or 0.0, empty=empty)
     _engine.op_project_ex(desc, points_dev, points_dev.shape[1], points_dev.shape[0], ring_dev, None,
                           labels_dev, lut_dev, self.image, self._idx, self._scratch,
-                          torch.cuda.current_stream(self._dev).cuda_stream)
+                          _engine.stream_handle(self._dev))
     self._points_dev = points_dev
     return self.image
 
@@ -180,7 +180,7 @@ def pcl_xyz_i_r_d_l_to_information_map(pcl, H=32, W=240, C=7, leftPhi=np.radians
   if C != 7:
     raise ValueError("the reference writes 7 channels")
   pcl = np.asarray(pcl)
-  dev = torch.device("cuda", device)
+  dev = _engine.torch_device(device)
   pts = torch.from_numpy(np.ascontiguousarray(pcl[:, :4], np.float32)).to(dev)
   ring = torch.from_numpy(np.ascontiguousarray(pcl[:, 4].astype(int), np.int32)).to(dev)
   depth = torch.from_numpy(np.ascontiguousarray(pcl[:, 5], np.float32)).to(dev)
@@ -191,5 +191,5 @@ def pcl_xyz_i_r_d_l_to_information_map(pcl, H=32, W=240, C=7, leftPhi=np.radians
                                 winner=_engine.PROJ_LAST, out_channels=7, left_phi=float(leftPhi),
                                 right_phi=float(rightPhi), empty=0.0)
   _engine.op_project_ex(desc, pts, 4, pts.shape[0], ring, depth, label, None, image, None, scratch,
-                        torch.cuda.current_stream(dev).cuda_stream)
+                        _engine.stream_handle(dev))
   return image.cpu().numpy().astype(np.float64)

@@ -43,7 +43,7 @@ def main():
   with tempfile.TemporaryDirectory() as tmp:
     for i, lib in enumerate(libs):
       out = os.path.join(tmp, "out%d.npz" % i)
-      env = dict(os.environ, PCLSEG_LIB=lib)
+      env = dict(os.environ, PCLSEG_LIB=lib, PCLSEG_DEBUG="1")
       subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", out], env=env)
       outs.append(dict(np.load(out)))
   bad = 0

@@ -1,0 +1,600 @@
+// hipsim — a functional CPU stand-in for <hip/hip_runtime.h>, for TESTS ONLY.
+//
+// This header is test infrastructure, like oracle/: it lets the UNMODIFIED kernel and host sources of
+// pclsegmentation_amd/csrc be compiled for x86-64 (sim/Makefile -> sim/_build/libpclseg_sim*.so) so that the
+// wave-level algorithms — fragment packing, LDS staging, MFMA lane maps, cross-lane reductions, barrier placement,
+// the host's launch geometry and stream logic — can be executed, checked against the oracle, run under
+// AddressSanitizer and compared between two builds when no MI355X is available (GPU sanitizers are not offered on
+// this pool).  It is NOT a CPU path of the product: pclsegmentation_amd/engine.py never loads a simulator library
+// (only tests/ do, through tests/simlib.py), nothing here is timed by bench.py, and a result obtained here is never
+// quoted as a hardware measurement.  What it cannot tell: anything about speed, register pressure, instruction
+// scheduling, wait counts or the rounding inside an MFMA (see mfma below).
+//
+// Execution model.  A launch runs its grid to completion before hipLaunchKernelGGL returns (streams and events are
+// trivially ordered).  The blocks of a grid are dealt to a pool of OS threads.  Inside a block every HIP thread is
+// a fiber (own stack, hand-rolled context switch); a fiber runs until it reaches
+//   * a workgroup barrier (__syncthreads, pclseg::lds_barrier) — it waits for every unfinished fiber of the block;
+//   * a wave-level operation (MFMA, __shfl_xor, DPP, readfirstlane) — it deposits its operands and waits until no
+//     fiber of its 64-lane wave can run any more; the scheduler then evaluates the operation for the lanes that
+//     arrived (the active mask) and hands each its result;
+//   * its end.
+// So lanes of a wave are NOT in lockstep between two such points: code that exchanges data through LDS inside one
+// wave without a barrier or wave operation in between (legal on the hardware) would read stale data here.  The
+// run order of waves and of lanes inside a wave is chosen by HIPSIM_ORDER=fwd|rev|rand:<seed>, so a missing
+// barrier shows up as results that depend on the order.  LDS is filled with 0xFF bytes (float NaN) before every
+// block and a guard zone behind the launch's dynamic LDS size is checked after it.
+//
+// MFMA arithmetic: v_mfma_f32_16x16x4_f32 is a float32 fmaf chain over k = 0..3 (what the hardware does, DESIGN.md
+// §3); v_mfma_f32_16x16x32_f16 multiplies exactly (an f16 x f16 product fits a float32) and accumulates with one
+// float32 rounding per k in ascending k — the hardware's internal order and width are not documented, so results
+// of the f16 path agree with the MI355X only to rounding noise, while two builds that issue the same MFMAs on the
+// same operands agree bit for bit here exactly when they do on the hardware.
+#pragma once
+#ifndef PCLSEG_SIM
+#define PCLSEG_SIM 1
+#endif
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <cxxabi.h>
+#include <dlfcn.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+// ---- language ---------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ thread_local
+
+struct dim3 {
+  uint32_t x, y, z;
+  constexpr dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace pclseg {
+// every kernel declares `extern __shared__ ... unsigned char smem_raw[]`: the block's dynamic LDS
+thread_local __attribute__((aligned(128))) unsigned char smem_raw[160 * 1024 + 4096];
+}
+
+// ---- runtime API --------------------------------------------------------------------------------------------------
+typedef int hipError_t;
+enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
+struct hipsimStream { int id; };
+struct hipsimEvent { int id; };
+typedef hipsimStream* hipStream_t;
+typedef hipsimEvent* hipEvent_t;
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0;
+
+namespace hipsim {
+
+struct Registry {
+  std::mutex mu;
+  std::map<uintptr_t, size_t> device, pinned;   // base -> bytes
+  size_t device_bytes = 0, device_limit = (size_t)16 << 30;
+  static Registry& get() { static Registry r; return r; }
+  static bool inside(const std::map<uintptr_t, size_t>& m, const void* p) {
+    auto it = m.upper_bound((uintptr_t)p);
+    if (it == m.begin()) return false;
+    --it;
+    return (uintptr_t)p < it->first + it->second;
+  }
+};
+
+inline hipError_t alloc(void** p, size_t n, bool dev) {
+  Registry& r = Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (dev && r.device_bytes + n > r.device_limit) return hipErrorOutOfMemory;
+  void* q = nullptr;
+  if (posix_memalign(&q, 4096, n ? n : 1) != 0) return hipErrorOutOfMemory;
+  memset(q, 0xFF, n);   // fresh memory is garbage on the device too; NaN-fill makes a read of it visible
+  (dev ? r.device : r.pinned)[(uintptr_t)q] = n ? n : 1;
+  if (dev) r.device_bytes += n;
+  *p = q;
+  return hipSuccess;
+}
+inline hipError_t release(void* p, bool dev) {
+  if (!p) return hipSuccess;
+  Registry& r = Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  auto& m = dev ? r.device : r.pinned;
+  auto it = m.find((uintptr_t)p);
+  if (it == m.end()) return hipErrorInvalidValue;
+  if (dev) r.device_bytes -= it->second;
+  m.erase(it);
+  free(p);
+  return hipSuccess;
+}
+
+}  // namespace hipsim
+
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t e) {
+  return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory (hipsim)" : e == hipErrorInvalidValue ? "invalid argument (hipsim)" : "error (hipsim)";
+}
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { return hipsim::alloc(p, n, true); }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipsim::alloc((void**)p, n, true); }
+inline hipError_t hipFree(void* p) { return hipsim::release(p, true); }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipsim::alloc(p, n, false); }
+template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f) { return hipsim::alloc((void**)p, n, false); }
+inline hipError_t hipHostFree(void* p) { return hipsim::release(p, false); }
+inline hipError_t hipHostRegister(void* p, size_t n, unsigned) {
+  auto& r = hipsim::Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  r.pinned[(uintptr_t)p] = n;
+  return hipSuccess;
+}
+inline hipError_t hipHostUnregister(void* p) {
+  auto& r = hipsim::Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  return r.pinned.erase((uintptr_t)p) ? hipSuccess : hipErrorInvalidValue;
+}
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) {
+  auto& r = hipsim::Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (!hipsim::Registry::inside(r.pinned, h)) return hipErrorInvalidValue;
+  *d = h;
+  return hipSuccess;
+}
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* at, const void* p) {
+  auto& r = hipsim::Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  at->device = 0;
+  at->devicePointer = at->hostPointer = const_cast<void*>(p);
+  if (hipsim::Registry::inside(r.pinned, p)) { at->type = hipMemoryTypeHost; return hipSuccess; }
+  if (hipsim::Registry::inside(r.device, p)) { at->type = hipMemoryTypeDevice; return hipSuccess; }
+  return hipErrorInvalidValue;   // pageable host memory: what HIP reports for an address it has never seen
+}
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipsimStream{1}; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipsimEvent{1}; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+template <class F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+
+// ---- blocks, waves, fibers ----------------------------------------------------------------------------------------
+extern "C" void hipsim_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipsim_switch
+.type hipsim_switch,@function
+hipsim_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipsim_switch,.-hipsim_switch
+)");
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPSIM_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
+namespace hipsim {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+enum State : int { READY = 0, AT_BARRIER = 1, AT_WAVE_OP = 2, DONE = 3 };
+enum OpKind : int { OP_SHFL_XOR = 1, OP_READFIRST = 2, OP_DPP = 3, OP_MFMA_F16 = 4, OP_MFMA_F32 = 5 };
+
+constexpr int kMaxThreads = 1024;
+constexpr size_t kStackBytes = 256 * 1024;
+constexpr size_t kLdsGuard = 4096;
+
+struct Fiber {
+  void* sp = nullptr;
+  char* stack = nullptr;
+  State state = DONE;
+  int op = 0, op_arg = 0;
+  union { unsigned char in[48]; struct { v8h a, b; v4f c; } m16; struct { float a, b; v4f c; } m32; uint32_t u; };
+  union { unsigned char out[16]; v4f outv; uint32_t outu; };
+  Fiber() {}
+};
+
+struct Worker {
+  Fiber* fibers = nullptr;
+  void* sched_sp = nullptr;
+  const void* sched_stack = nullptr;   // (AddressSanitizer: bounds of the scheduler's own stack)
+  size_t sched_stack_bytes = 0;
+  Fiber* cur = nullptr;
+  const std::function<void()>* body = nullptr;
+  uint64_t rng = 0;
+};
+inline thread_local Worker* tl_worker = nullptr;
+
+[[noreturn]] inline void die(const char* msg) {
+  fprintf(stderr, "hipsim: %s (block %u,%u,%u thread %u)\n", msg, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+  if (FILE* f = fopen(getenv("HIPSIM_LOG") ? getenv("HIPSIM_LOG") : "/tmp/hipsim_abort.log", "a")) {   // (a test runner may have captured stderr)
+    fprintf(f, "hipsim: %s (block %u,%u,%u thread %u)\n", msg, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+    fclose(f);
+  }
+  abort();
+}
+
+inline void yield_to_scheduler(State st) {
+  Worker* w = tl_worker;
+  Fiber* f = w->cur;
+  f->state = st;
+#ifdef HIPSIM_ASAN
+  void* fake = nullptr;
+  __sanitizer_start_switch_fiber(st == DONE ? nullptr : &fake, w->sched_stack, w->sched_stack_bytes);
+#endif
+  hipsim_switch(&f->sp, w->sched_sp);
+#ifdef HIPSIM_ASAN
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+}
+
+inline void fiber_main() {
+  Worker* w = tl_worker;
+#ifdef HIPSIM_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &w->sched_stack, &w->sched_stack_bytes);
+#endif
+  (*w->body)();
+  yield_to_scheduler(DONE);
+  die("a finished fiber was resumed");
+}
+
+inline void fiber_reset(Fiber& f) {
+  // stack as hipsim_switch expects it: six callee-saved registers, then the return address (fiber_main), laid out
+  // so that rsp % 16 == 8 on entry to fiber_main, as after a call
+  uintptr_t top = ((uintptr_t)f.stack + kStackBytes) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 8);
+  *--sp = (void*)&fiber_main;
+  for (int i = 0; i < 6; ++i) *--sp = nullptr;
+  f.sp = sp;
+  f.state = READY;
+}
+
+// ---- wave operations (evaluated by the scheduler for the lanes that arrived) ------------------------------------
+inline void mfma_f16(Fiber* lane) {
+  float A[16][32], B[32][16], D[16][16];
+  for (int l = 0; l < 64; ++l) {
+    const int r = l & 15, k0 = 8 * (l >> 4);
+    for (int j = 0; j < 8; ++j) { A[r][k0 + j] = (float)lane[l].m16.a[j]; B[k0 + j][r] = (float)lane[l].m16.b[j]; }
+    for (int i = 0; i < 4; ++i) D[4 * (l >> 4) + i][r] = lane[l].m16.c[i];
+  }
+  for (int i = 0; i < 16; ++i)
+    for (int k = 0; k < 32; ++k) {
+      const float a = A[i][k];
+#pragma clang loop vectorize(enable)
+      for (int j = 0; j < 16; ++j) D[i][j] = __builtin_fmaf(a, B[k][j], D[i][j]);
+    }
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < 4; ++i) lane[l].outv[i] = D[4 * (l >> 4) + i][l & 15];
+}
+inline void mfma_f32(Fiber* lane) {
+  float A[16][4], B[4][16], D[16][16];
+  for (int l = 0; l < 64; ++l) {
+    A[l & 15][l >> 4] = lane[l].m32.a;
+    B[l >> 4][l & 15] = lane[l].m32.b;
+    for (int i = 0; i < 4; ++i) D[4 * (l >> 4) + i][l & 15] = lane[l].m32.c[i];
+  }
+  for (int i = 0; i < 16; ++i)
+    for (int k = 0; k < 4; ++k)
+      for (int j = 0; j < 16; ++j) D[i][j] = __builtin_fmaf(A[i][k], B[k][j], D[i][j]);
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < 4; ++i) lane[l].outv[i] = D[4 * (l >> 4) + i][l & 15];
+}
+
+inline int dpp_source(int lane, int ctrl) {
+  const int row = lane & ~15, q = lane & 15;
+  if (ctrl < 0x100) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);   // quad_perm
+  if (ctrl == 0x140) return row | (15 - q);                                  // row_mirror
+  if (ctrl == 0x141) return row | (q & 8) | (7 - (q & 7));                   // row_half_mirror
+  die("DPP control not modelled");
+}
+
+// all lanes of `lane[0..n)` with state AT_WAVE_OP and the same (op, op_arg) as the first such lane
+inline void resolve_wave_ops(Fiber* lane, int n) {
+  for (;;) {
+    int first = -1;
+    for (int l = 0; l < n; ++l) if (lane[l].state == AT_WAVE_OP) { first = l; break; }
+    if (first < 0) return;
+    const int op = lane[first].op, arg = lane[first].op_arg;
+    bool in[64];
+    int cnt = 0;
+    for (int l = 0; l < 64; ++l) { in[l] = l < n && lane[l].state == AT_WAVE_OP && lane[l].op == op && lane[l].op_arg == arg; cnt += in[l]; }
+    switch (op) {
+      case OP_MFMA_F16: if (cnt != 64) die("MFMA reached by a partial wave"); mfma_f16(lane); break;
+      case OP_MFMA_F32: if (cnt != 64) die("MFMA reached by a partial wave"); mfma_f32(lane); break;
+      case OP_SHFL_XOR:
+        for (int l = 0; l < 64; ++l) if (in[l]) { const int s = l ^ arg; lane[l].outu = (s < 64 && in[s]) ? lane[s].u : lane[l].u; }
+        break;
+      case OP_READFIRST:
+        for (int l = 0; l < 64; ++l) if (in[l]) lane[l].outu = lane[first].u;
+        break;
+      case OP_DPP:   // (old = 0, bound_ctrl: a disabled or invalid source lane reads as 0)
+        for (int l = 0; l < 64; ++l) if (in[l]) { const int s = dpp_source(l, arg); lane[l].outu = in[s] ? lane[s].u : 0u; }
+        break;
+      default: die("unknown wave operation");
+    }
+    for (int l = 0; l < 64; ++l) if (in[l]) lane[l].state = READY;
+  }
+}
+
+inline uint64_t next_rand(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+
+struct Order { int mode = 0; uint64_t seed = 1; };   // 0 fwd, 1 rev, 2 rand
+inline Order& order() {
+  static Order o = [] {
+    Order r;
+    const char* e = getenv("HIPSIM_ORDER");
+    if (e && !strncmp(e, "rev", 3)) r.mode = 1;
+    else if (e && !strncmp(e, "rand", 4)) { r.mode = 2; if (e[4] == ':') r.seed = strtoull(e + 5, nullptr, 10) * 2654435761ull + 1; }
+    return r;
+  }();
+  return o;
+}
+
+inline void make_perm(int* p, int n, int mode, uint64_t& rng) {
+  for (int i = 0; i < n; ++i) p[i] = mode == 1 ? n - 1 - i : i;
+  if (mode == 2) for (int i = n - 1; i > 0; --i) { const int j = (int)(next_rand(rng) % (uint64_t)(i + 1)); const int t = p[i]; p[i] = p[j]; p[j] = t; }
+}
+
+inline void run_block(Worker& w, const dim3 grid, const dim3 block, const dim3 bid, const size_t lds) {
+  const int nthreads = (int)(block.x * block.y * block.z);
+  const int nwaves = (nthreads + 63) / 64;
+  memset(pclseg::smem_raw, 0xFF, lds);
+  memset(pclseg::smem_raw + lds, 0xA5, kLdsGuard);
+  for (int t = 0; t < nthreads; ++t) fiber_reset(w.fibers[t]);
+  const int mode = order().mode;
+  int wperm[kMaxThreads / 64], lperm[64];
+  auto run = [&](int t) {
+    Fiber& f = w.fibers[t];
+    gridDim = grid; blockDim = block; blockIdx = bid;
+    threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    w.cur = &f;
+#ifdef HIPSIM_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, f.stack, kStackBytes);
+#endif
+    hipsim_switch(&w.sched_sp, f.sp);
+#ifdef HIPSIM_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+  };
+  for (;;) {
+    make_perm(wperm, nwaves, mode, w.rng);
+    for (int wi = 0; wi < nwaves; ++wi) {
+      const int w0 = wperm[wi] * 64, n = nthreads - w0 < 64 ? nthreads - w0 : 64;
+      for (;;) {
+        bool ran = false;
+        make_perm(lperm, n, mode, w.rng);
+        for (int li = 0; li < n; ++li) {
+          const int t = w0 + lperm[li];
+          if (w.fibers[t].state == READY) { run(t); ran = true; }
+        }
+        bool waiting = false;
+        for (int l = 0; l < n; ++l) waiting |= w.fibers[w0 + l].state == AT_WAVE_OP;
+        if (waiting) resolve_wave_ops(&w.fibers[w0], n);
+        else if (!ran) break;
+      }
+    }
+    int at_bar = 0;
+    for (int t = 0; t < nthreads; ++t) at_bar += w.fibers[t].state == AT_BARRIER;
+    if (!at_bar) break;
+    for (int t = 0; t < nthreads; ++t) if (w.fibers[t].state == AT_BARRIER) w.fibers[t].state = READY;
+  }
+  for (size_t i = 0; i < kLdsGuard; ++i)
+    if (pclseg::smem_raw[lds + i] != 0xA5) { blockIdx = bid; die("a block wrote LDS beyond the launch's dynamic size"); }
+}
+
+// One launch.  Workers hold it by shared_ptr and draw block numbers from ITS counter, so a worker that wakes up late
+// (after the launch has completed and the next one has begun) finds its own job exhausted and touches nothing else.
+struct Job {
+  dim3 grid, block;
+  size_t lds = 0;
+  const std::function<void()>* body = nullptr;
+  uint64_t total = 0;
+  std::atomic<uint64_t> next{0};
+  std::atomic<uint64_t> finished{0};
+};
+
+struct Pool {
+  std::mutex launch_mu, mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> threads;
+  uint64_t epoch = 0;
+  std::shared_ptr<Job> job;
+
+  static Pool& get() { static Pool* p = new Pool(); return *p; }   // (leaked on purpose: workers outlive static destructors)
+
+  Pool() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("HIPSIM_THREADS")) n = atoi(e);
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    for (int i = 0; i < n; ++i) threads.emplace_back([this, i] { worker(i); });
+    for (auto& t : threads) t.detach();
+  }
+
+  void worker(int index) {
+    Worker w;
+    w.fibers = new Fiber[kMaxThreads];
+    char* stacks = (char*)mmap(nullptr, kStackBytes * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == (char*)MAP_FAILED) { perror("hipsim: mmap(fiber stacks)"); abort(); }
+    for (int t = 0; t < kMaxThreads; ++t) w.fibers[t].stack = stacks + (size_t)t * kStackBytes;
+    w.rng = order().seed + 0x9E3779B97F4A7C15ull * (uint64_t)(index + 1);
+    tl_worker = &w;
+    uint64_t seen = 0;
+    for (;;) {
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return epoch != seen; });
+        seen = epoch;
+        j = job;
+      }
+      if (!j) continue;
+      uint64_t done = 0;
+      for (;;) {
+        const uint64_t b = j->next.fetch_add(1);
+        if (b >= j->total) break;     // (a block number below total is only ever handed out while launch() waits: body is alive)
+        w.body = j->body;
+        const dim3 g = j->grid;
+        const dim3 bid((uint32_t)(b % g.x), (uint32_t)((b / g.x) % g.y), (uint32_t)(b / ((uint64_t)g.x * g.y)));
+        run_block(w, g, j->block, bid, j->lds);
+        ++done;
+      }
+      if (done && j->finished.fetch_add(done) + done == j->total) {
+        std::lock_guard<std::mutex> lk(mu);
+        cv_done.notify_all();
+      }
+    }
+  }
+
+  void launch(dim3 g, dim3 b, size_t l, const std::function<void()>& fn) {
+    std::lock_guard<std::mutex> one(launch_mu);
+    if ((uint64_t)b.x * b.y * b.z > (uint64_t)kMaxThreads || l > 160 * 1024) { fprintf(stderr, "hipsim: launch with %u threads / %zu B of LDS\n", b.x * b.y * b.z, l); abort(); }
+    auto j = std::make_shared<Job>();
+    j->grid = g; j->block = b; j->lds = l; j->body = &fn;
+    j->total = (uint64_t)g.x * g.y * g.z;
+    if (!j->total) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = j;
+      ++epoch;
+    }
+    cv_work.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return j->finished.load() == j->total; });
+    job.reset();
+  }
+};
+
+// HIPSIM_TRACE=<file>: one line per launch — demangled kernel, grid, threads per block, dynamic LDS bytes (what
+// tests/test_sim.py compares with pclseg_plan_ops, and which kernel instantiations a test run executed)
+inline void trace_launch(const void* kernel, dim3 g, dim3 b, size_t lds) {
+  static const char* path = getenv("HIPSIM_TRACE");
+  if (!path || !*path) return;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  Dl_info info;
+  const char* sym = (dladdr(kernel, &info) && info.dli_sname) ? info.dli_sname : "?";
+  int status = 0;
+  char* dem = abi::__cxa_demangle(sym, nullptr, nullptr, &status);
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s\t%u\t%u\t%u\t%u\t%zu\n", status == 0 && dem ? dem : sym, g.x, g.y, g.z, b.x * b.y * b.z, lds);
+    fclose(f);
+  }
+  free(dem);
+}
+
+template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t, const void* kernel, F&& f) {
+  trace_launch(kernel, g, b, lds);
+  const std::function<void()> fn(f);
+  Pool::get().launch(g, b, lds, fn);
+}
+
+// ---- what kernels call --------------------------------------------------------------------------------------------
+inline void barrier() { yield_to_scheduler(AT_BARRIER); }
+
+inline uint32_t wave_u32(OpKind op, int arg, uint32_t v) {
+  Fiber* f = tl_worker->cur;
+  f->op = op; f->op_arg = arg; f->u = v;
+  yield_to_scheduler(AT_WAVE_OP);
+  return tl_worker->cur->outu;
+}
+template <class T> inline T shfl_xor(T v, int mask) {
+  static_assert(sizeof(T) == 4, "32-bit shuffles only");
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u = wave_u32(OP_SHFL_XOR, mask, u);
+  memcpy(&v, &u, 4);
+  return v;
+}
+inline v4f mfma16(v8h a, v8h b, v4f c) {
+  Fiber* f = tl_worker->cur;
+  f->op = OP_MFMA_F16; f->op_arg = 0; f->m16.a = a; f->m16.b = b; f->m16.c = c;
+  yield_to_scheduler(AT_WAVE_OP);
+  return tl_worker->cur->outv;
+}
+inline v4f mfma32(float a, float b, v4f c) {
+  Fiber* f = tl_worker->cur;
+  f->op = OP_MFMA_F32; f->op_arg = 0; f->m32.a = a; f->m32.b = b; f->m32.c = c;
+  yield_to_scheduler(AT_WAVE_OP);
+  return tl_worker->cur->outv;
+}
+
+}  // namespace hipsim
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  hipsim::launch((grid), (block), (size_t)(lds), (stream), (const void*)(kernel), [&] { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { hipsim::barrier(); }
+template <class T> inline T __shfl_xor(T v, int mask) { return hipsim::shfl_xor(v, mask); }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }
+struct uint4 { unsigned x, y, z, w; };
+
+// (functions, not macros: call sites pass compound literals with commas)
+inline hipsim::v4f __builtin_amdgcn_mfma_f32_16x16x32_f16(hipsim::v8h a, hipsim::v8h b, hipsim::v4f c, int, int, int) { return hipsim::mfma16(a, b, c); }
+inline hipsim::v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipsim::v4f c, int, int, int) { return hipsim::mfma32(a, b, c); }
+#define __builtin_amdgcn_readfirstlane(v) ((int)hipsim::wave_u32(hipsim::OP_READFIRST, 0, (uint32_t)(v)))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bound) ((int)hipsim::wave_u32(hipsim::OP_DPP, (ctrl), (uint32_t)(src)))
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_s_memtime() ((unsigned long long)__builtin_ia32_rdtsc())
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+
+template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicMin(T* p, T v) {
+  T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o;
+}
+template <class T> inline T atomicMax(T* p, T v) {
+  T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o;
+}

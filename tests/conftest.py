@@ -8,19 +8,50 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 
+SIM = os.environ.get("PCLSEG_SIM")      # functional-simulator mode of the GPU suite: tests/simlib.py
+if SIM:
+  import simlib
+  simlib.activate(SIM)
+
+
 def pytest_configure(config):
   config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+  config.addinivalue_line("markers", "first_hw_run: not yet run on an MI355X (GPU access closed since it was written): ordered last")
+  config.addinivalue_line("markers", "needs_hip: uses torch.cuda / RCCL / the HIP runtime itself; skipped in simulator mode")
+
+
+def pytest_collection_modifyitems(config, items):
+  # tests that have not yet passed once on an MI355X run LAST: the driver uses `pytest -x`, and a first-run surprise
+  # in a new test must not hide the verified suite behind it (they are ordinary strict tests, never xfail)
+  items.sort(key=lambda it: "first_hw_run" in it.keywords)
+  if SIM:
+    skip = pytest.mark.skip(reason="simulator mode: needs the real HIP runtime")
+    for it in items:
+      if "needs_hip" in it.keywords:
+        it.add_marker(skip)
+
+
+def host_tensor(shape, dtype, pinned=False):
+  """Host-side tensor for the MEM_HOST / MEM_HOST_ASYNC boundary tests."""
+  import torch
+  if SIM:
+    return simlib.host_tensor(shape, dtype, pinned)
+  t = torch.empty(shape, dtype=dtype)
+  return t.pin_memory() if pinned else t
+
+
+def device_sync(dev):
+  """torch.cuda.synchronize for a real device; the simulator runs every launch to completion."""
+  import torch
+  if dev.type == "cuda":
+    torch.cuda.synchronize(dev)
 
 
 @pytest.fixture(scope="session")
 def cuda():
   import torch
+  if SIM:   # "device" memory is host memory
+    return torch.device("cpu")
   if not torch.cuda.is_available():
     pytest.fail("this test is marked gpu and needs a HIP device; run CPU suites with -m 'not gpu'")
   return torch.device("cuda:0")
-
-
-# Tests written while the builder had no GPU access carry this mark until they have passed once on an MI355X: the
-# driver runs `pytest -m gpu -x`, and a first-run surprise in a NEW test must not hide the verified suite behind it.
-# strict=False: a pass is reported as XPASS; the mark is removed as soon as scripts/run2.sh has been green on hardware.
-unverified_on_gpu = pytest.mark.xfail(strict=False, reason="added in round 4 after the builder's GPU access ended: not yet run on an MI355X")

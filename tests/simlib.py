@@ -1,0 +1,62 @@
+"""Functional-simulator mode of the GPU suite (test infrastructure, like oracle/).
+
+    PCLSEG_SIM=1 python -m pytest tests -m gpu          # the GPU tests on sim/_build/libpclseg_sim.so
+    PCLSEG_SIM=asan ...                                  # AddressSanitizer build (needs LD_PRELOAD, see sim/Makefile)
+
+sim/ compiles the UNMODIFIED sources of pclsegmentation_amd/csrc for x86-64 against a stand-in <hip/hip_runtime.h>
+(fibers for HIP threads, wave operations evaluated per 64-lane wave, LDS per block): the wave-level algorithms and
+the host code run, and are checked, without an MI355X.  What that is worth and what it is not is stated in
+sim/hip/hip_runtime.h.  The product never loads a simulator library: engine.py takes another binary only under
+PCLSEG_DEBUG=1 + PCLSEG_LIB, which this module sets for the test process, and "device" tensors are CPU tensors
+(the simulator's device memory is host memory) through the three seams engine.torch_device / stream_handle /
+on_device."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_DIR = os.path.join(ROOT, "sim")
+TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asan.so"), "r4x": ("r4x", "libpclseg_sim_r4x.so")}
+
+
+def library(variant="1"):
+  """Path of the simulator build `variant`, (re)built by make when a source is newer."""
+  target, name = TARGETS[variant]
+  subprocess.check_call(["make", "-s", "-C", SIM_DIR, target])
+  return os.path.join(SIM_DIR, "_build", name)
+
+
+def activate(variant="1"):
+  """Point engine.py at the simulator library and make CPU tensors stand in for device tensors.
+  Must run before pclsegmentation_amd.engine is imported."""
+  os.environ["PCLSEG_LIB"] = library(variant)
+  os.environ["PCLSEG_DEBUG"] = "1"
+  import torch
+  from pclsegmentation_amd import engine as E
+  assert E.DEBUG_LIB and E.LIB_PATH == os.environ["PCLSEG_LIB"]
+  E.torch_device = lambda index=0: torch.device("cpu")
+  E.stream_handle = lambda device=None: 0
+  # every torch tensor is "device" memory, except the ones host_tensor() below handed out; NumPy arrays are host
+  E.on_device = lambda x: hasattr(x, "data_ptr") and x.data_ptr() not in _HOST
+  E.is_pinned = lambda x: _HOST.get(x.data_ptr(), False)
+  return E
+
+
+_HOST = {}     # data_ptr -> pinned?
+
+
+def host_tensor(shape, dtype, pinned):
+  """A CPU tensor that the simulator-mode seams treat as HOST memory; pinned ones come from pclseg_host_alloc (the
+  simulator's registry of page-locked memory, which hipHostGetDevicePointer / hipPointerGetAttributes consult)."""
+  import ctypes
+  import numpy as np
+  import torch
+  from pclsegmentation_amd import engine as E
+  t = torch.empty(shape, dtype=dtype)
+  if pinned:
+    nbytes = max(1, t.numel() * t.element_size())
+    p = E.load_library().pclseg_host_alloc(nbytes)
+    assert p, "pclseg_host_alloc failed"
+    buf = (ctypes.c_uint8 * nbytes).from_address(p)     # (never freed: a test process)
+    t = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8)).view(dtype)[:t.numel()].view(shape)
+  _HOST[t.data_ptr()] = bool(pinned)
+  return t

@@ -5,18 +5,23 @@ import subprocess
 
 import pytest
 
+from conftest import SIM
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "pclsegmentation_amd")
+LIBNAME = "libpclseg.so"
+if SIM:      # simulator mode (tests/simlib.py): the same C program, linked with the x86-64 build of the same sources
+  LIBDIR, LIBNAME = os.path.split(os.environ["PCLSEG_LIB"])
 
 
 @pytest.fixture(scope="module")
 def consumer(tmp_path_factory):
-  if not os.path.isfile(os.path.join(LIBDIR, "libpclseg.so")):
+  if not os.path.isfile(os.path.join(LIBDIR, LIBNAME)):
     pytest.fail("libpclseg.so is not built (run `make`)")
   exe = str(tmp_path_factory.mktemp("c_abi") / "consumer")
   subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1",
                          "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "consumer.c"),
-                         "-L", LIBDIR, "-lpclseg", "-lm", "-Wl,-rpath," + LIBDIR, "-o", exe])
+                         "-L", LIBDIR, "-l:" + LIBNAME, "-lm", "-Wl,-rpath," + LIBDIR, "-o", exe])
   return exe
 
 

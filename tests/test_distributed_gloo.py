@@ -104,6 +104,68 @@ def test_broadcast_engine_failure_on_the_source_rank_raises_everywhere():
   assert "rank 0 could not build the engine" in res[1]
 
 
+class _FakeEngine:
+  """Stands in for engine.Engine on a box without a GPU: only the control flow of broadcast_engine is under test."""
+  def __init__(self, desc=None, nbytes=64):
+    self.nbytes = nbytes
+  def packed_size(self):
+    return self.nbytes
+  def export_packed(self, blob):
+    blob.fill_(7)
+  def import_packed(self, blob):
+    self.got = int(blob.sum())
+  def close(self):
+    pass
+
+
+def _failing_dst_worker(rank, world, port, q, mode):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                    LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+  import pclsegmentation_amd as P
+  from pclsegmentation_amd import engine as E
+  D.init_process_group(backend="gloo")
+  _, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+  model.engine = lambda h, w, flags=0: _FakeEngine()
+  model.engine_desc = lambda h, w, flags=0: None
+  model.adopt_engine = lambda eng, h, w, flags=0: None
+  if mode == "create_fails":
+    def boom(desc):
+      raise MemoryError("pclseg: hipMalloc(activation arena): out of memory")
+    E.Engine = boom if rank == 2 else _FakeEngine
+  else:       # this rank's plan packs a different number of bytes
+    E.Engine = (lambda desc: _FakeEngine(nbytes=80)) if rank == 1 else _FakeEngine
+  try:
+    D.broadcast_engine(model, 32, 240, src=0)
+    q.put((rank, "returned"))
+  except (RuntimeError, MemoryError) as e:
+    q.put((rank, "%s: %s" % (type(e).__name__, e)))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_broadcast_engine_failure_on_a_receiving_rank_raises_everywhere():
+  """A NON-source rank cannot create its receiving engine (out of memory) or packs a different size: the MIN
+  all-reduce that follows the status broadcast makes every rank raise and name the failing rank — rank 0 is not
+  left waiting in the blob's broadcast."""
+  for mode, world, bad, text in (("create_fails", 3, 2, "out of memory"), ("size_differs", 2, 1, "this rank's plan needs 80")):
+    with socket.socket() as s:
+      s.bind(("127.0.0.1", 0))
+      port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_dst_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+      p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+      p.join(60)
+      assert p.exitcode == 0
+    assert text in res[bad], res
+    for r in range(world):
+      if r != bad:
+        assert "rank %d could not create its receiving engine" % bad in res[r], res
+
+
 def _one_rank_worker(port, q):
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                     PCLSEG_FORCE_COLLECTIVES="1")

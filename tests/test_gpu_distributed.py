@@ -36,6 +36,7 @@ def _rank_env():
   return env
 
 
+@pytest.mark.needs_hip
 @pytest.mark.parametrize("world,n", [(2, 7), (8, 19)])   # 7 scans over 2 ranks: [0,4) [4,7); 19 over 8: ragged 3,3,3,2,...
 def test_engine_ranks_reproduce_the_single_process_result(cuda, tmp_path, world, n):
   h, w = 32, 240
@@ -69,6 +70,7 @@ def _torchrun(world, script_args, env, timeout=900):
   return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+@pytest.mark.needs_hip
 def test_one_rank_nccl_runs_the_rccl_transport(cuda, tmp_path):
   """The RCCL code path on the one GPU this box has: ONE rank under torch.distributed.run with the nccl
   backend and PCLSEG_FORCE_COLLECTIVES=1 — init_process_group's nccl branch, broadcast_engine's status
@@ -94,6 +96,47 @@ def test_one_rank_nccl_runs_the_rccl_transport(cuda, tmp_path):
   model._drop_engines()
 
 
+def _device_count():
+  import torch
+  return torch.cuda.device_count()      # (does not initialise HIP on this image)
+
+
+@pytest.mark.needs_hip
+@pytest.mark.first_hw_run
+@pytest.mark.skipif(_device_count() < 2, reason="needs two MI355X: arms itself on the first multi-GPU box")
+def test_two_rank_nccl_over_xgmi(cuda, tmp_path):
+  """The production N > 1 path on REAL devices: one rank per GPU, nccl (= RCCL) backend, NO forced collectives and no
+  gloo stand-in — broadcast_engine moves the packed parameters device to device over xGMI, each rank runs its
+  contiguous shard with no data-path collective, gather_predictions runs on the device.  Every rank's predictions
+  and logits must be bit-identical to the single-process result for its shard (the reference has no counterpart:
+  inference.py:116-118 is one process).  Skipped on a one-GPU box."""
+  world = min(_device_count(), 8)
+  h, w, n = 32, 240, 2 * world + 3          # ragged shards
+  env = _rank_env()
+  env.pop("PCLSEG_DIST_BACKEND")            # -> nccl
+  env.pop("PCLSEG_FORCE_COLLECTIVES", None)
+  r = _torchrun(world, [os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(n), str(h), str(w)], env, 900)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  mc, model = P.load_model_config("squeezesegv2", "squeezesegv2", height=h, width=w)
+  model.init_weights(4321)
+  raw = synthetic_scan_range(0, n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=99)
+  preds = np.empty((n, h, w), np.int32)
+  logits = np.empty((n, h, w, mc.NUM_CLASS), np.float32)
+  model.engine(h, w).forward_raw(raw, n, preds, None, logits, None, mem=E.MEM_HOST)
+  seen = np.zeros(n, bool)
+  for rank in range(world):
+    g = np.load(str(tmp_path / ("rank%d.npz" % rank)))
+    lo, hi = int(g["lo"]), int(g["hi"])
+    assert str(g["backend"]) == "nccl" and int(g["world"]) == world and (lo, hi) == D.shard_range(n, rank, world)
+    assert bool(g["engine_came_through_collective"]) == (rank != 0)
+    assert np.array_equal(g["preds"], preds[lo:hi]) and np.array_equal(g["logits"], logits[lo:hi]), "rank %d" % rank
+    seen[lo:hi] = True
+  assert seen.all()
+  assert np.array_equal(np.load(str(tmp_path / "gathered.npy")), preds)      # all_gather of device tensors, scan order
+  model._drop_engines()
+
+
+@pytest.mark.needs_hip
 def test_bench_one_rank_nccl_reduces_its_timings_on_the_device(cuda):
   """bench.py as the driver launches it for N > 1 (under torch.distributed.run), here with one forced rank:
   nccl process group, broadcast_engine through RCCL, barrier-fenced timed region, all_reduce(MAX) of the
@@ -109,6 +152,7 @@ def test_bench_one_rank_nccl_reduces_its_timings_on_the_device(cuda):
   assert out["value"] > 0 and out["n_gpus"] == 1
 
 
+@pytest.mark.needs_hip
 def test_c4_full_size_256_scans_over_8_ranks(cuda, tmp_path):
   """BASELINE configs[3] (C4) functionally: 256 scans of 64x2048 (SqueezeSegV2, 20 classes) sharded over 8
   fresh rank processes — 32 scans each, one packed-parameter broadcast, no data-path collective.  The ranks
@@ -139,6 +183,7 @@ def test_c4_full_size_256_scans_over_8_ranks(cuda, tmp_path):
   model._drop_engines()
 
 
+@pytest.mark.needs_hip
 def test_bench_c4_strong_scaling_full_size(cuda):
   """`bench.py --gpus 8 --scaling strong --global-batch 256` at the headline shape: the driver's C4 command
   line, with the 8 ranks sharing one GPU (functional check of the launch, sharding and reduction)."""
@@ -155,6 +200,7 @@ def test_bench_c4_strong_scaling_full_size(cuda):
   assert out["config"]["collectives"]["backend"] == "gloo" and out["value"] > 0
 
 
+@pytest.mark.needs_hip
 def test_bench_launches_its_own_ranks(cuda):
   """`python bench.py --gpus 2` outside torchrun starts its rank processes itself (the driver's
   launch line for N > 1 without torch.distributed.run) and prints ONE JSON line for the job."""
@@ -171,6 +217,7 @@ def test_bench_launches_its_own_ranks(cuda):
   assert out["value"] > 0 and out["scaling"] == "weak" and "roofline" in out
 
 
+@pytest.mark.needs_hip
 def test_bench_strong_scaling_mode(cuda):
   """`--scaling strong`: a FIXED global batch sharded over the ranks by contiguous ranges (SURVEY.md §8(e),
   BASELINE configs[3] is 256 scans over 8 GPUs); here 10 scans over 4 ranks sharing the one GPU."""
@@ -199,7 +246,7 @@ def test_packed_parameters_round_trip(cuda):
     want_p, want_l = np.empty((3, h, w), np.int32), np.empty((3, h, w, mc.NUM_CLASS), np.float32)
     src.forward_raw(raw, 3, want_p, None, want_l, None, mem=E.MEM_HOST)
     nbytes = src.packed_size()
-    for blob in (np.empty(nbytes, np.uint8), torch.empty(nbytes, dtype=torch.uint8, device="cuda")):
+    for blob in (np.empty(nbytes, np.uint8), torch.empty(nbytes, dtype=torch.uint8, device=cuda)):
       src.export_packed(blob)
       dst = E.Engine(model.engine_desc(h, w, flags))
       dst.import_packed(blob)

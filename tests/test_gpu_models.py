@@ -14,6 +14,7 @@ import pclsegmentation_amd as P
 from oracle import np_oracle as O
 from pclsegmentation_amd import engine as E
 from pclsegmentation_amd.utils.synthetic import synthetic_scans
+from conftest import device_sync, host_tensor
 
 pytestmark = pytest.mark.gpu
 
@@ -121,9 +122,9 @@ def test_model_call_surface(cuda):
   # raw entry point agrees with the reference-shaped one
   assert np.array_equal(model.predict_raw(raw).numpy(), predictions.numpy())
   # device tensors in -> device tensors out, same numbers
-  pt, pr = model([torch.from_numpy(lidar).cuda(), torch.from_numpy(mask).cuda()])
-  torch.cuda.synchronize()
-  assert pr.is_cuda and np.array_equal(pr.cpu().numpy(), predictions.numpy())
+  pt, pr = model([torch.from_numpy(lidar).to(cuda), torch.from_numpy(mask).to(cuda)])
+  device_sync(cuda)
+  assert E.on_device(pr) and np.array_equal(pr.cpu().numpy(), predictions.numpy())
   assert np.array_equal(pt.cpu().numpy(), probabilities.numpy())
   with pytest.raises(ValueError):
     model([lidar[:, :, :200], mask[:, :, :200]])          # W % 16 != 0
@@ -365,9 +366,9 @@ def test_split_f16_range_guard_and_exact_fallback(cuda):
   for flags, expect_error in ((0, True), (E.FLAG_RANGE_FALLBACK, False)):
     model._drop_engines()
     eng = model.engine(32, 240, flags)
-    d_raw = torch.from_numpy(raw).cuda()
-    d_preds = torch.empty((2, 32, 240), dtype=torch.int32, device="cuda")
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_raw = torch.from_numpy(raw).to(cuda)
+    d_preds = torch.empty((2, 32, 240), dtype=torch.int32, device=cuda)
+    eng.set_stream(E.stream_handle(cuda))
     eng.forward_raw(d_raw, 2, d_preds, None, None, None, mem=E.MEM_DEVICE)
     if expect_error:
       with pytest.raises(FloatingPointError):
@@ -399,10 +400,10 @@ def test_range_fallback_repairs_every_unsynced_call(cuda):
   run_engine(model, cold)                                 # the premise: the cold scan alone stays in range
   model._drop_engines()
   eng = model.engine(32, 240, E.FLAG_RANGE_FALLBACK)
-  eng.set_stream(torch.cuda.current_stream().cuda_stream)
-  d_hot, d_cold = torch.from_numpy(hot).cuda(), torch.from_numpy(cold).cuda()
-  o1 = torch.full((2, 32, 240), -7, dtype=torch.int32, device="cuda")
-  o2 = torch.full((2, 32, 240), -7, dtype=torch.int32, device="cuda")
+  eng.set_stream(E.stream_handle(cuda))
+  d_hot, d_cold = torch.from_numpy(hot).to(cuda), torch.from_numpy(cold).to(cuda)
+  o1 = torch.full((2, 32, 240), -7, dtype=torch.int32, device=cuda)
+  o2 = torch.full((2, 32, 240), -7, dtype=torch.int32, device=cuda)
   eng.forward_raw(d_hot, 2, o1, None, None, None, mem=E.MEM_DEVICE)    # overflows
   eng.forward_raw(d_cold, 2, o2, None, None, None, mem=E.MEM_DEVICE)   # does not
   eng.sync()
@@ -419,7 +420,7 @@ def test_range_fallback_repairs_every_unsynced_call(cuda):
   # without the fallback the synchronous call reports the flag and says earlier calls are suspect
   model._drop_engines()
   eng = model.engine(32, 240, 0)
-  eng.set_stream(torch.cuda.current_stream().cuda_stream)
+  eng.set_stream(E.stream_handle(cuda))
   eng.forward_raw(d_hot, 2, o1, None, None, None, mem=E.MEM_DEVICE)
   with pytest.raises(FloatingPointError, match="asynchronous"):
     eng.forward_raw(np.ascontiguousarray(cold), 2, h_out, None, None, None, mem=E.MEM_HOST)
@@ -469,17 +470,16 @@ def test_host_boundary_pinned_and_pageable_agree_with_device(cuda):
   raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=17)
   model.micro_batch = 2
   eng = model.engine(h, w)
-  d_raw = torch.from_numpy(raw).cuda()
-  d_preds = torch.empty((n, h, w), dtype=torch.int32, device="cuda")
-  d_logits = torch.empty((n, h, w, mc.NUM_CLASS), dtype=torch.float32, device="cuda")
-  eng.set_stream(torch.cuda.current_stream().cuda_stream)
+  d_raw = torch.from_numpy(raw).to(cuda)
+  d_preds = torch.empty((n, h, w), dtype=torch.int32, device=cuda)
+  d_logits = torch.empty((n, h, w, mc.NUM_CLASS), dtype=torch.float32, device=cuda)
+  eng.set_stream(E.stream_handle(cuda))
   eng.forward_raw(d_raw, n, d_preds, None, d_logits, None, mem=E.MEM_DEVICE)
   eng.sync()
   want_p, want_l = d_preds.cpu().numpy(), d_logits.cpu().numpy()
   lidar, omask = O.normalize_and_mask(raw, mc.INPUT_MEAN, mc.INPUT_STD)
   for pinned in (True, False):
-    mk = (lambda *s, dtype: torch.empty(s, dtype=dtype).pin_memory()) if pinned else \
-         (lambda *s, dtype: torch.empty(s, dtype=dtype))
+    mk = lambda *s, dtype: host_tensor(s, dtype, pinned)
     h_raw = mk(n, h, w, 5, dtype=torch.float32)
     h_raw.copy_(torch.from_numpy(raw))
     h_preds, h_logits = mk(n, h, w, dtype=torch.int32), mk(n, h, w, mc.NUM_CLASS, dtype=torch.float32)

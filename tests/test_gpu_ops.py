@@ -15,7 +15,6 @@ import pytest
 from oracle import np_oracle as O
 from pclsegmentation_amd import engine as E
 
-from conftest import unverified_on_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -93,7 +92,7 @@ def test_conv2d(cuda, case, math):
   _conv2d_case(cuda, case, math)
 
 
-@unverified_on_gpu
+@pytest.mark.first_hw_run
 @pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("case", WIDE_1X1_CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_conv2d_wide_1x1(cuda, case, math):

@@ -142,7 +142,7 @@ def test_nearest_point_wins_and_empty_value(cuda):
   import torch
   pts = np.array([[10, 0, 0, 0.1], [5, 0, 0, 0.2], [20, 0, 0, 0.3], [0, 0, 0, 0.9]], np.float32)
   scan = LaserScan(True, 16, 64, 3.0, -25.0)
-  img = scan.project_device(torch.from_numpy(pts).cuda(), empty=0.0).cpu().numpy()
+  img = scan.project_device(torch.from_numpy(pts).to(cuda), empty=0.0).cpu().numpy()
   idx = scan.proj_idx
   assert (idx >= 0).sum() == 1 and idx.max() == 1          # the 5 m return occludes 10 m and 20 m
   y, x = np.argwhere(idx == 1)[0]

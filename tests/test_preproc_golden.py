@@ -10,7 +10,6 @@ import numpy as np
 import pytest
 
 from oracle import np_oracle as O
-from conftest import unverified_on_gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(p)[len("preproc_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "preproc_*.npz")))
@@ -38,7 +37,7 @@ def test_oracle_preprocessing_equals_the_reference_bit_for_bit(case):
 
 
 @pytest.mark.gpu
-@unverified_on_gpu
+@pytest.mark.first_hw_run
 @pytest.mark.parametrize("case", CASES)
 def test_device_preprocessing_equals_the_reference_bit_for_bit(cuda, case):
   import torch

@@ -1,0 +1,78 @@
+"""Checks that only the functional simulator can make (PCLSEG_SIM=1 python -m pytest tests -m gpu; skipped on a real
+device): what every launch of a forward pass actually asked for, against what pclseg_plan_ops says it will; results
+that must not depend on the order in which waves and lanes run; and which kernel instantiations the pass executed.
+tests/test_sim.py runs this file in simulator mode as part of the CPU suite."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import SIM
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not SIM, reason="simulator mode only (PCLSEG_SIM=1)")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+NETS = [("squeezesegv2", "squeezesegv2kitti", 64, 256, 0.78), ("squeezesegv2", "squeezesegv2", 32, 240, 0.84),
+        ("darknet21", "darknet21", 32, 128, 0.59), ("darknet53", "darknet53kitti", 16, 64, 0.78)]
+
+_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import conftest   # activates simulator mode from PCLSEG_SIM
+import pclsegmentation_amd as P
+from pclsegmentation_amd import engine as E
+from pclsegmentation_amd.utils.synthetic import synthetic_scans
+model_name, cfg, h, w, pv, n, mb, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]
+mc, model = P.load_model_config(model_name, cfg, height=h, width=w)
+model.init_weights(4321)
+model.micro_batch = mb
+raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, pv, seed=5)
+preds = np.empty((n, h, w), np.int32)
+logits = np.empty((n, h, w, mc.NUM_CLASS), np.float32)
+eng = model.engine(h, w)
+open(sys.argv[9], "w").close()      # the trace starts here: finalize's packing kernels (if any) are not part of a pass
+eng.forward_raw(raw, n, preds, None, logits, None, mem=E.MEM_HOST)
+np.savez(out, preds=preds, logits=logits)
+"""
+
+
+def _forward_in_child(tmp_path, net, n, mb, tag, **env):
+  """One forward pass in a fresh process (HIPSIM_* are read once per process) -> (outputs, launch trace)."""
+  out, trace = str(tmp_path / ("out_%s.npz" % tag)), str(tmp_path / ("trace_%s.txt" % tag))
+  e = dict(os.environ, HIPSIM_TRACE=trace, **env)
+  subprocess.check_call([sys.executable, "-c", _CHILD % {"root": ROOT}, net[0], net[1], str(net[2]), str(net[3]), str(net[4]),
+                         str(n), str(mb), out, trace], env=e, cwd=ROOT)
+  rows = [l.rstrip("\n").split("\t") for l in open(trace)]
+  return dict(np.load(out)), [(r[0], int(r[1]) * int(r[2]) * int(r[3]), int(r[4]), int(r[5])) for r in rows]
+
+
+@pytest.mark.parametrize("net", NETS, ids=["%s_%dx%d" % (n[1], n[2], n[3]) for n in NETS])
+def test_every_launch_asks_for_what_plan_ops_says(tmp_path, net):
+  """pclseg_plan_ops derives LDS bytes / threads / blocks per scan from the graph with its own copy of the launchers'
+  expressions (the three-lane residency analysis of DESIGN.md §12 rests on it).  The simulator sees the real launch
+  arguments: one scan, one micro-batch — launch k of the pass must be row k of the plan."""
+  import pclsegmentation_amd as P
+  from pclsegmentation_amd import engine as E
+  _, launches = _forward_in_child(tmp_path, net, 1, 1, "plan")
+  mc, model = P.load_model_config(net[0], net[1], height=net[2], width=net[3])
+  model.micro_batch = 1
+  plan = E.plan_op_resources(model.engine_desc(net[2], net[3]))
+  launches = [l for l in launches if "normalize_kernel" not in l[0]]          # pre-processing precedes the op list
+  assert len(launches) == len(plan), (len(launches), len(plan), [l[0][:60] for l in launches], [p[0] for p in plan])
+  for (kernel, blocks, threads, lds), (name, _macs, p_lds, p_threads, p_blocks) in zip(launches, plan):
+    assert (blocks, threads, lds) == (p_blocks, p_threads, p_lds), \
+      "%s: launched %s with %d blocks x %d threads, %d B LDS; plan_ops says %d x %d, %d B" % (
+        name, kernel[:80], blocks, threads, lds, p_blocks, p_threads, p_lds)
+
+
+@pytest.mark.parametrize("net", NETS[1:3], ids=["%s_%dx%d" % (n[1], n[2], n[3]) for n in NETS[1:3]])
+def test_results_do_not_depend_on_the_order_waves_and_lanes_run_in(tmp_path, net):
+  """A missing barrier (a wave reading LDS another wave has not yet written) makes the result depend on the schedule.
+  Forward, reverse and two random orders of waves within a block and lanes within a wave: bit-identical outputs."""
+  ref, _ = _forward_in_child(tmp_path, net, 3, 2, "fwd", HIPSIM_ORDER="fwd")
+  for order in ("rev", "rand:1", "rand:2"):
+    got, _ = _forward_in_child(tmp_path, net, 3, 2, order.replace(":", ""), HIPSIM_ORDER=order)
+    assert np.array_equal(got["preds"], ref["preds"]) and np.array_equal(got["logits"].view(np.uint32), ref["logits"].view(np.uint32)), order
