@@ -396,7 +396,6 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
-#ifdef PCLSEG_R4X_GEOM2
   // fire4 (32 -> 128 + 128 -> 32, 4 x 16-pixel tiles, WN = 8): conv_kernel GEOM 2
   if (op.mtw == 4 && op.ntw == 1 && op.wn == 8 && a.fsq_q == 32 && epi == 0 && op.cin_t == 32 && a.in_s16 && a.PW == 18 && a.PH == 6 &&
       op.ck16 >= 32 && !op.up_fused) {
@@ -405,7 +404,6 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
-#endif
 #define PCLSEG_X(M_, N_, W_, Q_, E_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16 && epi == E_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_>; \
@@ -433,7 +431,6 @@ hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStrea
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
-#ifdef PCLSEG_R4X_GEOM2
   // fire11 (32-channel up-convolved patch, 8 x 16-pixel tiles, WN = 4): conv_kernel GEOM 2
   if (op.mtw == 4 && op.ntw == 1 && op.wn == 4 && op.nw == 8 && nq == 1 && epi == 1 && op.cin_t == 32 && a.PW == 18 && a.PH == 10 &&
       op.ck16 >= 32) {   // (one chunk: 40 halfs per staged pixel and plane)
@@ -442,7 +439,6 @@ hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStrea
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
-#endif
 #define PCLSEG_X(M_, N_, W_, Q_, E_, U_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == 8 && nq == Q_ && epi == E_ && op.cin_t == 16 * U_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_, U_>; \
@@ -507,6 +503,19 @@ struct StampDump {
   }
 };
 #endif
+
+// Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1, float32 input, no fused operands) run on
+// conv1x1_wide_kernel: launch_conv and pclseg_plan_ops both ask here, and tests/test_sim_only.py compares the plan
+// with the launches the simulator sees.
+bool op_is_wide_1x1(const Op& op, bool in_s16, bool has_residual, bool has_skip) {
+  return op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.ck16 == 64 && op.cin_t % 64 == 0 && op.cin_t >= 128 &&
+         op.sub[0].nctp % 8 == 0 && op.sub[0].cout == op.sub[0].nctp * 16 && !in_s16 && !has_residual && !has_skip;
+}
+// -> cout tiles per wave (1 | 2) and blocks along the cout axis
+void wide_1x1_geom(const Op& op, int* nt, int* ny) {
+  *nt = op.sub[0].nctp % 16 == 0 ? 2 : 1;
+  *ny = op.sub[0].nctp / (8 * *nt);
+}
 
 // Fill the geometry of `a` (tensor pointers already set) from `op` and launch.
 // w32 / w16 / bias are the bases the sub-op offsets are relative to.
@@ -617,9 +626,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
     if (exact) return hipErrorInvalidValue;
     size_t slab = (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float);   // rows padded by 4 floats
-#ifdef PCLSEG_R4X_SLAB
     if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (size_t)8 * op.mtw * 16 * (2 * 16 + 4) * sizeof(float);   // two passes (conv_kernel NPASS)
-#endif
     lds = std::max(lds, slab);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
   } else if (lds > 64 * 1024) return hipErrorInvalidValue;
@@ -640,14 +647,12 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     static const int gm = tune_env("PCLSEG_GROUP_MAJOR", -1);
     a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
   }
-#ifdef PCLSEG_R4X_WIDE
   // Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): the software-pipelined GEMM kernel
-  if (!exact && op_is_flat(op) && op.nsub == 1 && op.kind == OP_CONV && op.ck16 == 64 && op.cin_t % 64 == 0 && op.cin_t >= 128 &&
-      op.sub[0].nctp % 8 == 0 && op.sub[0].cout == op.sub[0].nctp * 16 && !a.in_s16 && !a.res1 && !a.res2 && !a.skx && w16) {
+  if (!exact && w16 && op_is_wide_1x1(op, a.in_s16 != 0, a.res1 || a.res2, a.skx != nullptr)) {
     static const int wide_on = tune_env("PCLSEG_WIDE1X1", 1);
     if (wide_on) {
-      const int nt = op.sub[0].nctp % 16 == 0 ? 2 : 1;
-      const int ny_w = op.sub[0].nctp / (8 * nt);
+      int nt, ny_w;
+      wide_1x1_geom(op, &nt, &ny_w);
       a.ny = ny_w;
       a.sub[0].ny = ny_w;
       if (ny_w == 1) a.group_major = 0;
@@ -662,7 +667,6 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
       return hipGetLastError();
     }
   }
-#endif
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
 #ifdef PCLSEG_WITH_STAMPS
   StampDump stamp_dump(op.name(), &a.stamps, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split
@@ -1582,7 +1586,13 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
       same_pad(Wc, op.pkw, op.sw, &wo2, &pl2);
       const int wconv = op.ow_mul == 2 ? Wc : wo2;
       threads = op.nw * 64;
-      if (direct) {
+      if (!direct && op_is_wide_1x1(op, g.tensors[op.in].fmt == FMT_S16, op.res1 >= 0 || op.res2 >= 0, op.sk_in >= 0)) {
+        int nt, ny_w;
+        wide_1x1_geom(op, &nt, &ny_w);
+        lds = kW1Lds;
+        threads = 512;
+        blocks = (((int64_t)ti.H * ti.W + kW1Px - 1) / kW1Px) * ny_w;
+      } else if (direct) {
         const bool splitk = op.cin_t >= 256 && op.sub[0].nctp >= 3;
         lds = splitk ? (int64_t)4 * 2 * op.sub[0].nctp * 1024 : 0;
         const int px = splitk ? 32 : 4 * (op.sub[0].nctp == 4 ? 1 : 2) * 16;
@@ -1593,9 +1603,7 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
         if (op.up_fused) lds = ((lds + 15) & ~(int64_t)15) + (int64_t)t.PH * (t.PW / 2 + 1) * (2 * op.cin_t + kPadF16) * 2;
         if (op.fsq_fused) {
           int64_t slab = (int64_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * 4;
-#ifdef PCLSEG_R4X_SLAB
           if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (int64_t)8 * op.mtw * 16 * (2 * 16 + 4) * 4;
-#endif
           lds = std::max<int64_t>(lds, slab);
         }
         int ny = 0;

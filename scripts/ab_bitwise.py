@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Do two builds of the library produce BIT-IDENTICAL outputs?  The round-4 kernel variants (make r4x) re-order
+"""Do two builds of the library produce BIT-IDENTICAL outputs?  Kernel variants that only re-order
 memory traffic, not arithmetic: every accumulator still receives the same products in the same order, so logits and
 predictions must equal the shipped library's bit for bit on all three networks.
 

@@ -15,7 +15,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_DIR = os.path.join(ROOT, "sim")
-TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asan.so"), "r4x": ("r4x", "libpclseg_sim_r4x.so")}
+TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asan.so")}
 
 
 def library(variant="1"):

@@ -74,7 +74,7 @@ CONV_CASES = [
   (1, 3, 130, 4, 20, 1, 1, "none", True, False, False),      # cout 20 -> padded tile
 ]
 # Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): flat pixels, 128-pixel tiles (ragged last tile),
-# 2 .. 16 channel chunks, one to four cout groups — the shapes conv1x1_wide_kernel (make r4x) takes over
+# 2 .. 16 channel chunks, one to four cout groups — the shapes conv1x1_wide_kernel takes
 WIDE_1X1_CASES = [
   (1, 8, 40, 256, 128, 1, 1, "leaky", False, True, False),   # enc3-like: 8 cout tiles, 320 px = 2.5 tiles
   (2, 4, 33, 128, 256, 1, 1, "leaky", False, True, False),   # dec3-like: 2 chunks, 16 cout tiles, 264 px

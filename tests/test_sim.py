@@ -1,0 +1,49 @@
+"""CPU suite: a slice of the GPU tests, run on the functional simulator (sim/, tests/simlib.py).
+
+The kernels and the host code of pclsegmentation_amd/csrc are compiled UNMODIFIED for x86-64 and executed wave by wave:
+operator parity (both arithmetic modes, the wide 1x1 kernel included), whole networks against the oracle's golden
+vectors, every intermediate tensor of SqueezeSegV2, the fused plan on ragged shapes, the host boundary, the C consumer,
+launch geometry against pclseg_plan_ops, and independence of the wave / lane schedule.  This is a functional check — it
+says nothing about speed and does not replace the run on an MI355X (`python -m pytest tests -m gpu` there); the whole
+GPU suite runs here with `PCLSEG_SIM=1 python -m pytest tests -m gpu` (about ten minutes on 8 cores)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sim_pytest(args, timeout):
+  env = dict(os.environ, PCLSEG_SIM="1")
+  env.pop("PCLSEG_LIB", None)
+  r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                     capture_output=True, text=True, timeout=timeout)
+  tail = (r.stdout.strip().splitlines() or [""])[-1]
+  m = re.search(r"(\d+) passed", tail)
+  assert r.returncode == 0 and m and "failed" not in tail and "error" not in tail, r.stdout[-3000:] + r.stderr[-2000:]
+  return int(m.group(1))
+
+
+@pytest.fixture(scope="module")
+def simulator():
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import simlib
+  return simlib.library("1")      # make -C sim (about 40 s when a source changed)
+
+
+def test_operator_suite_on_the_simulator(simulator):
+  assert _sim_pytest(["tests/test_gpu_ops.py"], 600) >= 67
+
+
+def test_networks_host_boundary_and_c_consumer_on_the_simulator(simulator):
+  k = ("(golden and f16x3 and (ssv2_32x240 or ssv2_real or darknet53kitti)) or (intermediate and squeezesegv2 and f16x3)"
+       " or fully_fused or nan_pixel or range_fallback or host_boundary or c_consumer_forward")
+  assert _sim_pytest(["tests/test_gpu_models.py", "tests/test_c_abi.py", "-k", k], 1500) >= 19
+
+
+def test_launch_geometry_and_schedule_independence_on_the_simulator(simulator):
+  k = "(plan_ops and (squeezesegv2_32x240 or darknet53kitti)) or (order and squeezesegv2_32x240)"
+  assert _sim_pytest(["tests/test_sim_only.py", "-k", k], 900) >= 3
