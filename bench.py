@@ -37,6 +37,10 @@ WORKLOADS = {
   "darknet21_32x1024": ("darknet21", "darknet21", 32, 1024, 64, 0.59, "mfma"),
   "ssv2_32x240": ("squeezesegv2", "squeezesegv2", 32, 240, 32, 0.84, "hbm"),
 }
+# the other single-GPU configurations of BASELINE.json timed in the secondary rows: (workload, steps, warm-up)
+SECONDARY = (("darknet53_64x2048", 20, 4), ("darknet21_32x1024", 20, 4))
+# workloads of the parity_check rows (one full-size scan each against the float64 oracle)
+PARITY_WORKLOADS = ("ssv2_64x2048", "darknet53_64x2048", "darknet21_32x1024")
 
 
 def _cpu_leg(net, mc, raw, threads, batch, budget_s, max_scans):
@@ -131,7 +135,7 @@ def aux_rows(args):
   from oracle import np_oracle as O      # CPU baseline leg only
   if not torch.cuda.is_available():
     raise SystemExit("bench.py --aux needs an MI355X; there is no CPU fallback")
-  dev = torch.device("cuda", 0)
+  dev = E.torch_device(0)
   stream = torch.cuda.current_stream(dev)
   rng = np.random.default_rng(1234)
 
@@ -364,7 +368,7 @@ def parity_check(P, E, synthetic_weights, synthetic_scans, workload, dev, dev_in
     eng = model.engine(h, w, flags)
     preds = torch.empty((1, h, w), dtype=torch.int32, device=dev)
     logits = torch.empty((1, h, w, mc.NUM_CLASS), dtype=torch.float32, device=dev)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    eng.set_stream(E.stream_handle(dev))
     eng.forward_raw(d_raw, 1, preds, None, logits, None, mem=E.MEM_DEVICE)
     eng.sync()
     pr, lg = preds.cpu().numpy()[0], logits.cpu().numpy()[0].astype(np.float64)
@@ -468,7 +472,7 @@ def main():
     raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
   dev_index = local_rank % torch.cuda.device_count()   # identity on a node with one GPU per rank
   torch.cuda.set_device(dev_index)
-  dev = torch.device("cuda", dev_index)
+  dev = E.torch_device(dev_index)
   stream = torch.cuda.current_stream(dev)
 
   coll = D.collectives_active()   # > 1 rank, or a forced one-rank group (PCLSEG_FORCE_COLLECTIVES=1: test aid)
@@ -600,7 +604,7 @@ def main():
     # ---- the other single-GPU configurations of BASELINE.json (parity-tested in tests/, timed here;
     # their bound is the matrix cores)
     out["secondary"] = []
-    for wl, st, wu in (("darknet53_64x2048", 20, 4), ("darknet21_32x1024", 20, 4)):
+    for wl, st, wu in SECONDARY:
       if wl == args.workload:
         continue
       y = run_workload(wl, st, wu)
@@ -620,7 +624,7 @@ def main():
       out["c1_gpu"] = c1
     # ---- parity evidence of this very build, outside every timed region
     out["parity_check"] = [parity_check(P, E, synthetic_weights, synthetic_scans, wl, dev, dev_index)
-                           for wl in ("ssv2_64x2048", "darknet53_64x2048", "darknet21_32x1024")]
+                           for wl in PARITY_WORKLOADS]
   if rank == 0:
     if world == 1 and args.cpu_seconds > 0:
       out["cpu_baseline"] = cpu_baseline(r["model_name"], r["mc"], r["weights"], r["h"], r["w"], r["pvalid"],

@@ -36,12 +36,20 @@ def activate(variant="1"):
   E.torch_device = lambda index=0: torch.device("cpu")
   E.stream_handle = lambda device=None: 0
   # every torch tensor is "device" memory, except the ones host_tensor() below handed out; NumPy arrays are host
-  E.on_device = lambda x: hasattr(x, "data_ptr") and x.data_ptr() not in _HOST
-  E.is_pinned = lambda x: _HOST.get(x.data_ptr(), False)
+  E.on_device = lambda x: hasattr(x, "data_ptr") and _host_range(x.data_ptr()) is None
+  E.is_pinned = lambda x: bool(_host_range(x.data_ptr()))
   return E
 
 
-_HOST = {}     # data_ptr -> pinned?
+_HOST = []     # (first byte, one past the last, pinned?) of every tensor host_tensor() handed out; views of them count
+
+
+def _host_range(ptr):
+  """-> pinned? of the host allocation that contains ptr, None if it is "device" memory."""
+  for lo, hi, pinned in _HOST:
+    if lo <= ptr < hi:
+      return pinned
+  return None
 
 
 def host_tensor(shape, dtype, pinned):
@@ -58,5 +66,5 @@ def host_tensor(shape, dtype, pinned):
     assert p, "pclseg_host_alloc failed"
     buf = (ctypes.c_uint8 * nbytes).from_address(p)     # (never freed: a test process)
     t = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8)).view(dtype)[:t.numel()].view(shape)
-  _HOST[t.data_ptr()] = bool(pinned)
+  _HOST.append((t.data_ptr(), t.data_ptr() + max(1, t.numel() * t.element_size()), bool(pinned)))
   return t

@@ -47,3 +47,9 @@ def test_networks_host_boundary_and_c_consumer_on_the_simulator(simulator):
 def test_launch_geometry_and_schedule_independence_on_the_simulator(simulator):
   k = "(plan_ops and (squeezesegv2_32x240 or darknet53kitti)) or (order and squeezesegv2_32x240)"
   assert _sim_pytest(["tests/test_sim_only.py", "-k", k], 900) >= 3
+
+
+def test_bench_py_end_to_end_on_the_simulator(simulator):
+  """bench.py's own code path (main, secondary rows, c1_gpu, parity_check, cpu_baseline) on shrunken workloads: the
+  line it prints has every field of the contract.  Its timings mean nothing here."""
+  assert _sim_pytest(["tests/test_sim_only.py", "-k", "bench_line"], 1500) == 1
