@@ -347,8 +347,12 @@ hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const 
       case 0: PCLSEG_GO(0); break;
       case 1: PCLSEG_GO(1); break;
       case 2: PCLSEG_GO(2); break;
+#ifdef PCLSEG_TUNING   // a fused skip branch outside a merged pair: only a tuning switch (PCLSEG_BIGTILE=0, PCLSEG_GEOM) gets here
       case 3: PCLSEG_GO(3); break;
       default: PCLSEG_GO(4); break;
+#else
+      default: return hipErrorInvalidValue;
+#endif
     }
   }
 #undef PCLSEG_GO
@@ -358,6 +362,7 @@ hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const 
 template <bool HEAD, bool F16>
 hipError_t launch_conv_cfg(int mtw, int ntw, int wn, int epi, dim3 grid, size_t lds, hipStream_t s,
                            const ConvArgs& a) {
+#ifdef PCLSEG_TUNING   // every tile shape: PCLSEG_GEOM=<layer>=ntw,wn,mtw picks any of them
 #define PCLSEG_LAUNCH(NTW_, WN_) \
   return mtw == 2 ? launch_conv_epi<2, NTW_, WN_, HEAD, F16>(epi, grid, lds, s, a) \
                   : launch_conv_epi<4, NTW_, WN_, HEAD, F16>(epi, grid, lds, s, a)
@@ -367,6 +372,23 @@ hipError_t launch_conv_cfg(int mtw, int ntw, int wn, int epi, dim3 grid, size_t 
   else if (wn == 1 && ntw == 3) { PCLSEG_LAUNCH(3, 1); }
   else if (wn == 1 && ntw == 4 && HEAD) { PCLSEG_LAUNCH(4, 1); }
 #undef PCLSEG_LAUNCH
+#else
+  // The shapes op_geometry (pclseg_graph.h) produces, and no others — a kernel that no plan can select is not built
+  // (profiles/r05_sim_kernel_coverage.txt listed 96 such instantiations, the ones with the largest spills among them):
+  //   WN = 2 or one cout tile: 4 segments per wave; WN = 1 with 2-3 tiles: 2 segments for a single sub-conv (and the
+  //   head, whose tile count is ceil(NUM_CLASS / 16) <= 4), 4 for two sub-convs (transposed convolution, un-merged pair).
+#define PCLSEG_LAUNCH(MTW_, NTW_, WN_) return launch_conv_epi<MTW_, NTW_, WN_, HEAD, F16>(epi, grid, lds, s, a)
+  if constexpr (!HEAD) { if (wn == 2 && ntw == 2 && mtw == 4) { PCLSEG_LAUNCH(4, 2, 2); } }
+  if (wn == 1 && ntw == 1 && mtw == 4) { PCLSEG_LAUNCH(4, 1, 1); }
+  if (wn == 1 && ntw == 2 && mtw == 2) { PCLSEG_LAUNCH(2, 2, 1); }
+  if (wn == 1 && ntw == 3 && mtw == 2) { PCLSEG_LAUNCH(2, 3, 1); }
+  if constexpr (HEAD) { if (wn == 1 && ntw == 4 && mtw == 2) { PCLSEG_LAUNCH(2, 4, 1); } }
+  if constexpr (!HEAD) {
+    if (wn == 1 && ntw == 2 && mtw == 4) { PCLSEG_LAUNCH(4, 2, 1); }
+    if (wn == 1 && ntw == 3 && mtw == 4) { PCLSEG_LAUNCH(4, 3, 1); }
+  }
+#undef PCLSEG_LAUNCH
+#endif
   return hipErrorInvalidValue;
 }
 
@@ -737,7 +759,9 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
 #endif
     }
     if (op.mtw == 4 && op.wn == 4) return launch_conv_epi<4, 2, 4, false, true, false, 8>(epi, grid, lds, s, a);
+#ifdef PCLSEG_TUNING   // (the uncapped 128 px x 256 couts kernel: PCLSEG_DN_VARIANT=0)
     if (op.mtw == 8 && op.wn == 8) return launch_conv_epi<8, 2, 8, false, true, false, 8>(epi, grid, lds, s, a);
+#endif
     return hipErrorInvalidValue;
   }
   if (op.kind == OP_HEAD)

@@ -124,6 +124,38 @@ def _conv2d_case(cuda, case, math):
   assert err <= 2e-5 * max(1.0, np.abs(y64).max()), err
 
 
+def _fuzz_cases(count, seed):
+  """Seeded random convolution shapes over the whole dispatch space of pclseg_op_conv2d: channel counts on both
+  sides of every chunk / cout-tile boundary, 1x1 and 3x3, both strides, ragged and tiny images, every epilogue."""
+  rng = np.random.default_rng(seed)
+  cins = [4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 320, 512, 1024]
+  couts = [4, 8, 16, 20, 32, 48, 64, 80, 96, 128, 192, 256, 512, 1024]
+  out = []
+  while len(out) < count:
+    k = int(rng.choice([1, 3]))
+    s = int(rng.choice([1, 2])) if k == 3 else 1
+    cin, cout = int(rng.choice(cins)), int(rng.choice(couts))
+    n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 11)), int(rng.integers(1, 141))
+    if n * h * w * k * k * cin * cout > 3e8:
+      continue
+    out.append((n, h, w, cin, cout, k, s, str(rng.choice(["none", "relu", "leaky", "sigmoid"])), bool(rng.integers(2)),
+                bool(rng.integers(2)), bool(rng.integers(2))))
+  return out
+
+
+@pytest.mark.first_hw_run
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("case", _fuzz_cases(160, 20261004), ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_fuzz(cuda, case, math):
+  """Every shape is either computed to the oracle's values or rejected with a shape error — never wrong, never a
+  crash, never a partly written output (the kernels behind the operator entry point are picked by a dispatch table
+  of tile shapes and epilogues of which the three networks use a fraction)."""
+  try:
+    _conv2d_case(cuda, case, math)
+  except ValueError as e:
+    assert "pclseg" in str(e), e
+
+
 def test_conv2d_stride2_known_answer(cuda):
   """row [1,2,3,4], k=3, s=2, kernel [1,10,100] -> [321, 43]
   (even W pads right only)."""
@@ -143,6 +175,35 @@ def test_conv2d_stride2_known_answer(cuda):
                          ids=str)
 @pytest.mark.parametrize("math", MATHS)
 def test_conv2d_transpose(cuda, case, math):
+  _conv2d_transpose_case(cuda, case, math)
+
+
+def _transpose_fuzz_cases(count, seed):
+  rng = np.random.default_rng(seed)
+  out = []
+  while len(out) < count:
+    cin = int(rng.choice([8, 16, 32, 48, 64, 96, 128, 256, 512, 1024]))
+    cout = int(rng.choice([8, 16, 32, 48, 64, 96, 128, 256, 512]))
+    n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 10)), int(rng.integers(1, 71))
+    if n * h * w * 4 * cin * cout > 3e8:
+      continue
+    out.append((n, h, w, cin, cout, str(rng.choice(["none", "relu", "leaky"])), bool(rng.integers(2))))
+  return out
+
+
+@pytest.mark.first_hw_run
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("case", _transpose_fuzz_cases(40, 20261005), ids=str)
+def test_conv2d_transpose_fuzz(cuda, case, math):
+  """Conv2DTranspose (1,4)/(1,2) over the dispatch space of its two parity sub-convolutions (FIREUP and the Darknet
+  decoder use four shapes of it): computed to the oracle's values or rejected with a shape error."""
+  try:
+    _conv2d_transpose_case(cuda, case, math)
+  except ValueError as e:
+    assert "pclseg" in str(e), e
+
+
+def _conv2d_transpose_case(cuda, case, math):
   import torch
   n, h, w, cin, cout, act, use_bn = case
   rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
@@ -202,8 +263,22 @@ def test_max_pool_known_answer(cuda):
 @pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("nc,cin,with_probs", [(11, 32, False), (20, 64, False), (20, 64, True), (11, 64, True)])
 def test_head(cuda, nc, cin, with_probs, math):
+  _head_case(cuda, nc, cin, with_probs, math, 2, 9, 37)
+
+
+@pytest.mark.first_hw_run
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("nc,cin,with_probs,n,h,w", [(2, 16, True, 1, 1, 1), (5, 32, False, 1, 3, 130), (16, 64, True, 2, 4, 33),
+                                                       (17, 32, False, 1, 7, 16), (33, 64, True, 1, 5, 48), (48, 32, False, 1, 2, 129),
+                                                       (64, 128, True, 1, 3, 20), (3, 256, False, 1, 6, 17)])
+def test_head_class_counts_and_shapes(cuda, nc, cin, with_probs, n, h, w, math):
+  """One to four 16-class tiles (NUM_CLASS 2 .. 64), counts on both sides of every tile boundary, single-pixel and
+  ragged images: the reference's configs use 4, 11, 20 and 34 classes."""
+  _head_case(cuda, nc, cin, with_probs, math, n, h, w)
+
+
+def _head_case(cuda, nc, cin, with_probs, math, n, h, w):
   import torch
-  n, h, w = 2, 9, 37
   rng = np.random.default_rng(nc * 1000 + cin + with_probs)
   x = rnd(rng, n, h, w, cin)
   kern = (rng.standard_normal((3, 3, cin, nc)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
