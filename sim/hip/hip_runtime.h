@@ -24,6 +24,14 @@
 // barrier shows up as results that depend on the order.  LDS is filled with 0xFF bytes (float NaN) before every
 // block and a guard zone behind the launch's dynamic LDS size is checked after it.
 //
+// Race detection (make -C sim race, sim/race_driver.cpp).  Built with -fsanitize=thread every WAVE is a ThreadSanitizer
+// fiber — the lanes of a wave share it, because on the hardware a wave is one instruction stream and its LDS / memory
+// operations are ordered by program order — and the only happens-before edges are the ones the hardware gives:
+// a workgroup barrier orders all waves of the block, a launch boundary orders everything, atomics are atomics.
+// TSan then reports an LDS location written by one wave and touched by another with no barrier in between, and
+// a global location touched by two blocks of one launch (blocks that run one after the other on the same worker are
+// ordered, so use more than one worker).  The simulator's own state lives in functions TSan does not instrument.
+//
 // MFMA arithmetic: v_mfma_f32_16x16x4_f32 is a float32 fmaf chain over k = 0..3 (what the hardware does, DESIGN.md
 // §3); v_mfma_f32_16x16x32_f16 multiplies exactly (an f16 x f16 product fits a float32) and accumulates with one
 // float32 rounding per k in ascending k — the hardware's internal order and width are not documented, so results
@@ -126,7 +134,14 @@ inline hipError_t release(void* p, bool dev) {
 
 }  // namespace hipsim
 
-inline hipError_t hipGetLastError() { return hipSuccess; }
+namespace hipsim {
+inline thread_local hipError_t last_error = hipSuccess;      // sticky until read, as hipGetLastError
+// kernels whose dynamic-LDS limit was raised above the 64 KB default (hipFuncSetAttribute): a launch that asks for
+// more without it fails on the device, so it fails here
+inline std::mutex& raised_mu() { static std::mutex m; return m; }
+inline std::map<const void*, int>& raised_lds() { static std::map<const void*, int> m; return m; }
+}
+inline hipError_t hipGetLastError() { const hipError_t e = hipsim::last_error; hipsim::last_error = hipSuccess; return e; }
 inline const char* hipGetErrorString(hipError_t e) {
   return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory (hipsim)" : e == hipErrorInvalidValue ? "invalid argument (hipsim)" : "error (hipsim)";
 }
@@ -180,7 +195,12 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-template <class F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+template <class F> inline hipError_t hipFuncSetAttribute(F fn, hipFuncAttribute attr, int value) {
+  if (attr != hipFuncAttributeMaxDynamicSharedMemorySize || value > 160 * 1024) return hipErrorInvalidValue;
+  std::lock_guard<std::mutex> lk(hipsim::raised_mu());
+  hipsim::raised_lds()[(const void*)fn] = value;
+  return hipSuccess;
+}
 
 // ---- blocks, waves, fibers ----------------------------------------------------------------------------------------
 extern "C" void hipsim_switch(void** save_sp, void* load_sp);
@@ -212,7 +232,13 @@ hipsim_switch:
 #define HIPSIM_ASAN 1
 #include <sanitizer/common_interface_defs.h>
 #endif
+#if __has_feature(thread_sanitizer)
+#define HIPSIM_TSAN 1
+#include <sanitizer/tsan_interface.h>
 #endif
+#endif
+// The scheduler's own bookkeeping is kept out of ThreadSanitizer's view (see "race detection" below)
+#define HIPSIM_NO_TSAN __attribute__((no_sanitize("thread")))
 
 namespace hipsim {
 
@@ -238,6 +264,11 @@ struct Fiber {
 
 struct Worker {
   Fiber* fibers = nullptr;
+#ifdef HIPSIM_TSAN
+  void* tsan_sched = nullptr;                 // the worker thread's own TSan context
+  void* tsan_wave[kMaxThreads / 64] = {};     // one TSan fiber per wave
+  char bar_obj = 0, start_obj = 0, end_obj = 0;   // addresses the happens-before edges hang on (block start: scheduler -> fibers; block end: fibers -> scheduler)
+#endif
   void* sched_sp = nullptr;
   const void* sched_stack = nullptr;   // (AddressSanitizer: bounds of the scheduler's own stack)
   size_t sched_stack_bytes = 0;
@@ -256,10 +287,15 @@ inline thread_local Worker* tl_worker = nullptr;
   abort();
 }
 
-inline void yield_to_scheduler(State st) {
+HIPSIM_NO_TSAN inline void yield_to_scheduler(State st) {
   Worker* w = tl_worker;
   Fiber* f = w->cur;
   f->state = st;
+#ifdef HIPSIM_TSAN
+  if (st == AT_BARRIER) __tsan_release(&w->bar_obj);
+  if (st == DONE) __tsan_release(&w->end_obj);
+  __tsan_switch_to_fiber(w->tsan_sched, __tsan_switch_to_fiber_no_sync);
+#endif
 #ifdef HIPSIM_ASAN
   void* fake = nullptr;
   __sanitizer_start_switch_fiber(st == DONE ? nullptr : &fake, w->sched_stack, w->sched_stack_bytes);
@@ -268,10 +304,16 @@ inline void yield_to_scheduler(State st) {
 #ifdef HIPSIM_ASAN
   __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
 #endif
+#ifdef HIPSIM_TSAN
+  if (st == AT_BARRIER) __tsan_acquire(&w->bar_obj);     // (every fiber of the block released before any was resumed)
+#endif
 }
 
-inline void fiber_main() {
+HIPSIM_NO_TSAN inline void fiber_main() {
   Worker* w = tl_worker;
+#ifdef HIPSIM_TSAN
+  __tsan_acquire(&w->start_obj);      // after the scheduler's block set-up (LDS fill), which follows the previous block on this worker
+#endif
 #ifdef HIPSIM_ASAN
   __sanitizer_finish_switch_fiber(nullptr, &w->sched_stack, &w->sched_stack_bytes);
 #endif
@@ -280,7 +322,7 @@ inline void fiber_main() {
   die("a finished fiber was resumed");
 }
 
-inline void fiber_reset(Fiber& f) {
+HIPSIM_NO_TSAN inline void fiber_reset(Fiber& f) {
   // stack as hipsim_switch expects it: six callee-saved registers, then the return address (fiber_main), laid out
   // so that rsp % 16 == 8 on entry to fiber_main, as after a call
   uintptr_t top = ((uintptr_t)f.stack + kStackBytes) & ~(uintptr_t)15;
@@ -292,7 +334,7 @@ inline void fiber_reset(Fiber& f) {
 }
 
 // ---- wave operations (evaluated by the scheduler for the lanes that arrived) ------------------------------------
-inline void mfma_f16(Fiber* lane) {
+HIPSIM_NO_TSAN inline void mfma_f16(Fiber* lane) {
   float A[16][32], B[32][16], D[16][16];
   for (int l = 0; l < 64; ++l) {
     const int r = l & 15, k0 = 8 * (l >> 4);
@@ -308,7 +350,7 @@ inline void mfma_f16(Fiber* lane) {
   for (int l = 0; l < 64; ++l)
     for (int i = 0; i < 4; ++i) lane[l].outv[i] = D[4 * (l >> 4) + i][l & 15];
 }
-inline void mfma_f32(Fiber* lane) {
+HIPSIM_NO_TSAN inline void mfma_f32(Fiber* lane) {
   float A[16][4], B[4][16], D[16][16];
   for (int l = 0; l < 64; ++l) {
     A[l & 15][l >> 4] = lane[l].m32.a;
@@ -331,7 +373,7 @@ inline int dpp_source(int lane, int ctrl) {
 }
 
 // all lanes of `lane[0..n)` with state AT_WAVE_OP and the same (op, op_arg) as the first such lane
-inline void resolve_wave_ops(Fiber* lane, int n) {
+HIPSIM_NO_TSAN inline void resolve_wave_ops(Fiber* lane, int n) {
   for (;;) {
     int first = -1;
     for (int l = 0; l < n; ++l) if (lane[l].state == AT_WAVE_OP) { first = l; break; }
@@ -377,15 +419,22 @@ inline void make_perm(int* p, int n, int mode, uint64_t& rng) {
   if (mode == 2) for (int i = n - 1; i > 0; --i) { const int j = (int)(next_rand(rng) % (uint64_t)(i + 1)); const int t = p[i]; p[i] = p[j]; p[j] = t; }
 }
 
-inline void run_block(Worker& w, const dim3 grid, const dim3 block, const dim3 bid, const size_t lds) {
+HIPSIM_NO_TSAN inline void run_block(Worker& w, const dim3 grid, const dim3 block, const dim3 bid, const size_t lds) {
   const int nthreads = (int)(block.x * block.y * block.z);
   const int nwaves = (nthreads + 63) / 64;
+#ifdef HIPSIM_TSAN
+  __tsan_acquire(&w.end_obj);        // the previous block's fibers are done with LDS
+  for (int i = 0; i < nwaves; ++i) if (!w.tsan_wave[i]) w.tsan_wave[i] = __tsan_create_fiber(0);
+#endif
   memset(pclseg::smem_raw, 0xFF, lds);
   memset(pclseg::smem_raw + lds, 0xA5, kLdsGuard);
   for (int t = 0; t < nthreads; ++t) fiber_reset(w.fibers[t]);
+#ifdef HIPSIM_TSAN
+  __tsan_release(&w.start_obj);
+#endif
   const int mode = order().mode;
   int wperm[kMaxThreads / 64], lperm[64];
-  auto run = [&](int t) {
+  auto run = [&](int t) HIPSIM_NO_TSAN {
     Fiber& f = w.fibers[t];
     gridDim = grid; blockDim = block; blockIdx = bid;
     threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
@@ -393,6 +442,9 @@ inline void run_block(Worker& w, const dim3 grid, const dim3 block, const dim3 b
 #ifdef HIPSIM_ASAN
     void* fake = nullptr;
     __sanitizer_start_switch_fiber(&fake, f.stack, kStackBytes);
+#endif
+#ifdef HIPSIM_TSAN
+    __tsan_switch_to_fiber(w.tsan_wave[t >> 6], __tsan_switch_to_fiber_no_sync);
 #endif
     hipsim_switch(&w.sched_sp, f.sp);
 #ifdef HIPSIM_ASAN
@@ -421,6 +473,9 @@ inline void run_block(Worker& w, const dim3 grid, const dim3 block, const dim3 b
     if (!at_bar) break;
     for (int t = 0; t < nthreads; ++t) if (w.fibers[t].state == AT_BARRIER) w.fibers[t].state = READY;
   }
+#ifdef HIPSIM_TSAN
+  __tsan_acquire(&w.end_obj);
+#endif
   for (size_t i = 0; i < kLdsGuard; ++i)
     if (pclseg::smem_raw[lds + i] != 0xA5) { blockIdx = bid; die("a block wrote LDS beyond the launch's dynamic size"); }
 }
@@ -462,6 +517,9 @@ struct Pool {
     for (int t = 0; t < kMaxThreads; ++t) w.fibers[t].stack = stacks + (size_t)t * kStackBytes;
     w.rng = order().seed + 0x9E3779B97F4A7C15ull * (uint64_t)(index + 1);
     tl_worker = &w;
+#ifdef HIPSIM_TSAN
+    w.tsan_sched = __tsan_get_current_fiber();
+#endif
     uint64_t seen = 0;
     for (;;) {
       std::shared_ptr<Job> j;
@@ -528,14 +586,24 @@ inline void trace_launch(const void* kernel, dim3 g, dim3 b, size_t lds) {
 
 template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t, const void* kernel, F&& f) {
   trace_launch(kernel, g, b, lds);
+  if (lds > 64 * 1024) {
+    std::lock_guard<std::mutex> lk(raised_mu());
+    auto it = raised_lds().find(kernel);
+    if (it == raised_lds().end() || (size_t)it->second < lds) {
+      fprintf(stderr, "hipsim: launch with %zu B of dynamic LDS without hipFuncSetAttribute(MaxDynamicSharedMemorySize)\n", lds);
+      last_error = hipErrorInvalidValue;
+      return;
+    }
+  }
+  if (b.x * b.y * b.z == 0 || b.x * b.y * b.z > 1024 || g.x == 0 || g.y == 0 || g.z == 0) { last_error = hipErrorInvalidValue; return; }
   const std::function<void()> fn(f);
   Pool::get().launch(g, b, lds, fn);
 }
 
 // ---- what kernels call --------------------------------------------------------------------------------------------
-inline void barrier() { yield_to_scheduler(AT_BARRIER); }
+HIPSIM_NO_TSAN inline void barrier() { yield_to_scheduler(AT_BARRIER); }
 
-inline uint32_t wave_u32(OpKind op, int arg, uint32_t v) {
+HIPSIM_NO_TSAN inline uint32_t wave_u32(OpKind op, int arg, uint32_t v) {
   Fiber* f = tl_worker->cur;
   f->op = op; f->op_arg = arg; f->u = v;
   yield_to_scheduler(AT_WAVE_OP);
@@ -549,13 +617,13 @@ template <class T> inline T shfl_xor(T v, int mask) {
   memcpy(&v, &u, 4);
   return v;
 }
-inline v4f mfma16(v8h a, v8h b, v4f c) {
+HIPSIM_NO_TSAN inline v4f mfma16(v8h a, v8h b, v4f c) {
   Fiber* f = tl_worker->cur;
   f->op = OP_MFMA_F16; f->op_arg = 0; f->m16.a = a; f->m16.b = b; f->m16.c = c;
   yield_to_scheduler(AT_WAVE_OP);
   return tl_worker->cur->outv;
 }
-inline v4f mfma32(float a, float b, v4f c) {
+HIPSIM_NO_TSAN inline v4f mfma32(float a, float b, v4f c) {
   Fiber* f = tl_worker->cur;
   f->op = OP_MFMA_F32; f->op_arg = 0; f->m32.a = a; f->m32.b = b; f->m32.c = c;
   yield_to_scheduler(AT_WAVE_OP);

@@ -53,3 +53,19 @@ def test_bench_py_end_to_end_on_the_simulator(simulator):
   """bench.py's own code path (main, secondary rows, c1_gpu, parity_check, cpu_baseline) on shrunken workloads: the
   line it prints has every field of the contract.  Its timings mean nothing here."""
   assert _sim_pytest(["tests/test_sim_only.py", "-k", "bench_line"], 1500) == 1
+
+
+def test_race_detector_controls_and_squeezesegv2():
+  """sim/race_driver (ThreadSanitizer, one TSan fiber per wave; barriers and launch boundaries are the only
+  happens-before edges): its five controls — two seeded races it must report, three clean patterns it must not — and
+  then SqueezeSegV2 forward passes in both arithmetic modes plus the projection / confusion-matrix operators with no
+  report.  (All three networks: `sim/_build/race_driver`; full benchmark sizes: `race_driver full`.)"""
+  subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sim"), "race"])
+  exe = os.path.join(ROOT, "sim", "_build", "race_driver")
+  env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=0")
+  r = subprocess.run([exe, "selftest"], capture_output=True, text=True, timeout=600, env=env)
+  rows = [l for l in r.stdout.splitlines() if l.startswith("selftest:")]
+  assert r.returncode == 0 and len(rows) == 5 and all("as it must be" in l for l in rows), r.stdout + r.stderr[-2000:]
+  assert sum("REPORTED" in l for l in rows) == 2
+  r = subprocess.run([exe, "ssv2", "ops"], capture_output=True, text=True, timeout=1500, env=env)
+  assert r.returncode == 0 and "0 ThreadSanitizer report(s)" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
