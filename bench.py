@@ -305,7 +305,14 @@ def roofline_of(bound, scans_per_s_dev, info):
   return roof
 
 
-TRAFFIC_JSON = os.environ.get("PCLSEG_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "r04_traffic.json")
+def _latest_traffic_json():
+  """profiles/rNN_traffic.json of the highest round (attach_traffic quotes it only for the binary it was measured on)."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+  return files[-1] if files else os.path.join(ROOT, "profiles", "r04_traffic.json")
+
+
+TRAFFIC_JSON = os.environ.get("PCLSEG_TRAFFIC_JSON") or _latest_traffic_json()
 REPEATS = 5       # the timed region (K steps, fenced) is measured this many times: `value` = median, `spread` = [min, max]
 
 

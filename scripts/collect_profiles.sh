@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copy the judged summaries of a profile round from gpurun_out/<round>/ (scratch) into profiles/ (tracked).
-# usage: collect_profiles.sh r04
+# usage: collect_profiles.sh r05
 cd "$(dirname "$0")/.."
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/$R
 [ -d "$O" ] || { echo "no $O (run scripts/profile_round.sh $R on the GPU box first)"; exit 1; }
 cp $O/bench.json profiles/${R}_bench.json

@@ -10,8 +10,9 @@
 // quoted as a hardware measurement.  What it cannot tell: anything about speed, register pressure, instruction
 // scheduling, wait counts or the rounding inside an MFMA (see mfma below).
 //
-// Execution model.  A launch runs its grid to completion before hipLaunchKernelGGL returns (streams and events are
-// trivially ordered).  The blocks of a grid are dealt to a pool of OS threads.  Inside a block every HIP thread is
+// Execution model.  Asynchronous operations are queued on their stream and run eagerly (default) or as late as the
+// stream / event dependencies allow (HIPSIM_STREAMS=lazy, see "streams and events" below); a grid, once it runs, runs to
+// completion.  The blocks of a grid are dealt to a pool of OS threads.  Inside a block every HIP thread is
 // a fiber (own stack, hand-rolled context switch); a fiber runs until it reaches
 //   * a workgroup barrier (__syncthreads, pclseg::lds_barrier) — it waits for every unfinished fiber of the block;
 //   * a wave-level operation (MFMA, __shfl_xor, DPP, readfirstlane) — it deposits its operands and waits until no
@@ -54,7 +55,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <deque>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -86,8 +89,8 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemc
 enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
-struct hipsimStream { int id; };
-struct hipsimEvent { int id; };
+struct hipsimStream;      // (defined with the stream model below)
+struct hipsimEvent;
 typedef hipsimStream* hipStream_t;
 typedef hipsimEvent* hipEvent_t;
 constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0;
@@ -148,13 +151,13 @@ inline const char* hipGetErrorString(hipError_t e) {
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { return hipsim::alloc(p, n, true); }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipsim::alloc((void**)p, n, true); }
-inline hipError_t hipFree(void* p) { return hipsim::release(p, true); }
+inline hipError_t hipDeviceSynchronize();
+inline hipError_t hipFree(void* p) { (void)hipDeviceSynchronize(); return hipsim::release(p, true); }      // (hipFree synchronises the device)
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipsim::alloc(p, n, false); }
 template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f) { return hipsim::alloc((void**)p, n, false); }
-inline hipError_t hipHostFree(void* p) { return hipsim::release(p, false); }
+inline hipError_t hipHostFree(void* p) { (void)hipDeviceSynchronize(); return hipsim::release(p, false); }
 inline hipError_t hipHostRegister(void* p, size_t n, unsigned) {
   auto& r = hipsim::Registry::get();
   std::lock_guard<std::mutex> lk(r.mu);
@@ -182,19 +185,6 @@ inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* at, const void*
   if (hipsim::Registry::inside(r.device, p)) { at->type = hipMemoryTypeDevice; return hipSuccess; }
   return hipErrorInvalidValue;   // pageable host memory: what HIP reports for an address it has never seen
 }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new hipsimStream{1}; return hipSuccess; }
-inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipsimEvent{1}; return hipSuccess; }
-inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 template <class F> inline hipError_t hipFuncSetAttribute(F fn, hipFuncAttribute attr, int value) {
   if (attr != hipFuncAttributeMaxDynamicSharedMemorySize || value > 160 * 1024) return hipErrorInvalidValue;
   std::lock_guard<std::mutex> lk(hipsim::raised_mu());
@@ -584,7 +574,9 @@ inline void trace_launch(const void* kernel, dim3 g, dim3 b, size_t lds) {
   free(dem);
 }
 
-template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t, const void* kernel, F&& f) {
+void enqueue(hipStream_t stream, std::function<void()> fn);      // (stream model, below)
+
+template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t stream, const void* kernel, F&& f) {
   trace_launch(kernel, g, b, lds);
   if (lds > 64 * 1024) {
     std::lock_guard<std::mutex> lk(raised_mu());
@@ -596,9 +588,171 @@ template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t, c
     }
   }
   if (b.x * b.y * b.z == 0 || b.x * b.y * b.z > 1024 || g.x == 0 || g.y == 0 || g.z == 0) { last_error = hipErrorInvalidValue; return; }
-  const std::function<void()> fn(f);
-  Pool::get().launch(g, b, lds, fn);
+  // the kernel's arguments are captured BY VALUE: in the lazy stream mode the grid runs when something waits for it
+  std::function<void()> body(std::forward<F>(f));
+  enqueue(stream, [g, b, lds, body] { Pool::get().launch(g, b, lds, body); });
 }
+
+// ---- streams and events ------------------------------------------------------------------------------------------
+// Every asynchronous operation is queued on its stream; a queue is drained in order, and a queued hipStreamWaitEvent
+// first drains the stream the event was recorded on up to the record.  HIPSIM_STREAMS chooses WHEN:
+//   eager (default)  an operation runs as soon as it is queued (a legal schedule: the earliest one);
+//   internal         the null stream (the caller's stream in the tests) runs eagerly, every stream the engine creates is lazy:
+//                    when an API call returns, everything the caller's stream was made to wait for has run and anything
+//                    the engine forgot to join into it has NOT — its outputs are missing, and inputs the caller frees
+//                    after the call are read too late, exactly as a caching allocator would let happen on the device;
+//   lazy             an operation runs only when something synchronises on it — hipStreamSynchronize,
+//                    hipEventSynchronize, hipDeviceSynchronize, hipFree, a synchronous hipMemcpy / hipMemset (these
+//                    run in the legacy null stream: they wait for the null stream only, NOT for the engine's
+//                    hipStreamNonBlocking streams) or a wait queued on a stream that is being drained — and only up to
+//                    the operation that is needed.  Also a legal schedule: the latest one.  A consumer whose producer it
+//                    never made itself dependent on then runs BEFORE the producer and reads stale (NaN-filled) data, a
+//                    staging buffer that is reused before the copy out of it was waited for is overwritten first: the
+//                    host-side ordering bugs that real hardware shows only under unlucky timing fail deterministically.
+// hipEventQuery answers from the model (lazy: not ready until drained).  hipsim_sync_stream() is exported for the test
+// harness: torch's `.cpu()` on a device tensor is a copy ordered after the current stream's work.
+}  // namespace hipsim
+
+struct hipsimStream {
+  struct Op {
+    std::function<void()> fn;            // kernel grid / copy / memset; empty for markers
+    hipsimStream* dep = nullptr;         // hipStreamWaitEvent: the stream of the event's last record ...
+    uint64_t dep_seq = 0;                // ... and the position of that record in it
+  };
+  std::deque<Op> q;
+  uint64_t done = 0, queued = 0;         // operations executed / ever queued
+};
+struct hipsimEvent { hipsimStream* stream = nullptr; uint64_t seq = 0; };
+
+namespace hipsim {
+
+struct Streams {
+  std::recursive_mutex mu;
+  hipsimStream null_stream;
+  std::set<hipsimStream*> all;
+  int lazy = 0;      // 0 eager, 1 internal (every stream but the null stream is lazy), 2 lazy (all)
+  static Streams& get() {
+    static Streams* s = [] {
+      auto* r = new Streams();
+      const char* e = getenv("HIPSIM_STREAMS");
+      r->lazy = e && !strcmp(e, "lazy") ? 2 : e && !strcmp(e, "internal") ? 1 : 0;
+      r->all.insert(&r->null_stream);
+      return r;
+    }();
+    return *s;
+  }
+  hipsimStream* of(hipStream_t s) { return s ? s : &null_stream; }
+  void drain(hipsimStream* s, uint64_t upto) {
+    while (s->done < upto && !s->q.empty()) {
+      hipsimStream::Op op = std::move(s->q.front());
+      s->q.pop_front();
+      if (op.dep && all.count(op.dep)) drain(op.dep, op.dep_seq);
+      if (op.fn) op.fn();
+      ++s->done;
+    }
+  }
+  void push(hipsimStream* s, hipsimStream::Op op) {
+    s->q.push_back(std::move(op));
+    ++s->queued;
+    if (lazy == 0 || (lazy == 1 && s == &null_stream)) drain(s, s->queued);
+  }
+};
+
+inline void enqueue(hipStream_t stream, std::function<void()> fn) {
+  Streams& st = Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  hipsimStream::Op op;
+  op.fn = std::move(fn);
+  st.push(st.of(stream), std::move(op));
+}
+
+}  // namespace hipsim
+
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags) {
+  if (!(flags & hipStreamNonBlocking)) { fprintf(stderr, "hipsim: blocking streams are not modelled\n"); return hipErrorInvalidValue; }
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  *s = new hipsimStream();
+  st.all.insert(*s);
+  return hipSuccess;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t s) {
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  st.drain(st.of(s), st.of(s)->queued);
+  return hipSuccess;
+}
+inline hipError_t hipStreamDestroy(hipStream_t s) {      // (the stream's queued work still completes)
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  if (!s || !st.all.count(s)) return hipErrorInvalidValue;
+  st.drain(s, s->queued);
+  st.all.erase(s);
+  delete s;
+  return hipSuccess;
+}
+inline hipError_t hipDeviceSynchronize() {
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  for (hipsimStream* s : std::vector<hipsimStream*>(st.all.begin(), st.all.end())) if (st.all.count(s)) st.drain(s, s->queued);
+  return hipSuccess;
+}
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipsimEvent(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }     // (queued waits hold the stream and position, not the event)
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) {
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  hipsimStream* q = st.of(s);
+  e->stream = q;
+  e->seq = q->queued + 1;      // (position of the marker queued next)
+  st.push(q, hipsimStream::Op());
+  return hipSuccess;
+}
+inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  hipsimStream::Op op;
+  if (e->stream && st.all.count(e->stream)) { op.dep = e->stream; op.dep_seq = e->seq; }      // (a never-recorded event: no dependency)
+  st.push(st.of(s), std::move(op));
+  return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t e) {
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  if (e->stream && st.all.count(e->stream)) st.drain(e->stream, e->seq);
+  return hipSuccess;
+}
+inline hipError_t hipEventQuery(hipEvent_t e) {
+  auto& st = hipsim::Streams::get();
+  std::lock_guard<std::recursive_mutex> lk(st.mu);
+  return (!e->stream || !st.all.count(e->stream) || e->stream->done >= e->seq) ? hipSuccess : hipErrorNotReady;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t stream = nullptr) {
+  hipsim::enqueue(stream, [d, s, n] { memmove(d, s, n); });
+  return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t stream = nullptr) {
+  hipsim::enqueue(stream, [d, v, n] { memset(d, v, n); });
+  return hipSuccess;
+}
+// synchronous copies run in the legacy null stream: ordered after the null stream's work, not after non-blocking streams
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+  (void)hipStreamSynchronize(nullptr);
+  memmove(d, s, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) {
+  (void)hipStreamSynchronize(nullptr);
+  memset(d, v, n);
+  return hipSuccess;
+}
+// test harness: what `tensor.cpu()` / torch.cuda.current_stream().synchronize() mean for the (null) current stream
+// (not inline: this header is the one translation unit's runtime, and the symbols must be in the library)
+extern "C" __attribute__((visibility("default"))) void hipsim_sync_stream(void* stream) { (void)hipStreamSynchronize((hipStream_t)stream); }
+extern "C" __attribute__((visibility("default"))) void hipsim_sync_device(void) { (void)hipDeviceSynchronize(); }
+extern "C" __attribute__((visibility("default"))) int hipsim_streams_lazy(void) { return hipsim::Streams::get().lazy; }
+
+namespace hipsim {
 
 // ---- what kernels call --------------------------------------------------------------------------------------------
 HIPSIM_NO_TSAN inline void barrier() { yield_to_scheduler(AT_BARRIER); }
@@ -633,7 +787,7 @@ HIPSIM_NO_TSAN inline v4f mfma32(float a, float b, v4f c) {
 }  // namespace hipsim
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  hipsim::launch((grid), (block), (size_t)(lds), (stream), (const void*)(kernel), [&] { kernel(__VA_ARGS__); })
+  hipsim::launch((grid), (block), (size_t)(lds), (stream), (const void*)(kernel), [=] { kernel(__VA_ARGS__); })
 
 inline void __syncthreads() { hipsim::barrier(); }
 template <class T> inline T __shfl_xor(T v, int mask) { return hipsim::shfl_xor(v, mask); }

@@ -65,6 +65,26 @@ static int run_selftest() {
     bad += reported != r.racy;
   }
   (void)hipFree(buf);
+  // ---- the stream model (HIPSIM_STREAMS): a consumer on the null stream with and without a dependency on its producer
+  {
+    hipStream_t side = nullptr;
+    hipEvent_t ev = nullptr;
+    unsigned char *dev = nullptr, host[2] = {0, 0};
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) || hipEventCreateWithFlags(&ev, hipEventDisableTiming) || hipMalloc(&dev, 64)) return 2;
+    (void)hipMemset(dev, 1, 64);
+    (void)hipMemsetAsync(dev, 2, 64, side);                      // producer on a side stream ...
+    (void)hipMemcpy(&host[0], dev, 1, hipMemcpyDeviceToHost);    // ... consumer on the null stream, NO dependency
+    (void)hipEventRecord(ev, side);
+    (void)hipStreamWaitEvent(nullptr, ev, 0);                    // now the null stream waits for the producer
+    (void)hipMemcpy(&host[1], dev, 1, hipMemcpyDeviceToHost);
+    const int mode = hipsim_streams_lazy();
+    const bool stale_seen = host[0] == 1, fresh_after_wait = host[1] == 2;
+    const bool ok = fresh_after_wait && (stale_seen == (mode != 0));
+    printf("selftest: %-40s %s (%s)\n", mode ? "stream model: un-joined producer" : "stream model: eager",
+           stale_seen ? "consumer ran first, saw stale data" : "consumer saw the producer's data", ok ? "as it must be" : "WRONG");
+    bad += !ok;
+    (void)hipStreamDestroy(side); (void)hipEventDestroy(ev); (void)hipFree(dev);
+  }
   return bad ? 3 : 0;
 }
 

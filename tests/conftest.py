@@ -45,6 +45,8 @@ def device_sync(dev):
   import torch
   if dev.type == "cuda":
     torch.cuda.synchronize(dev)
+  elif SIM:
+    simlib.sync_device()
 
 
 @pytest.fixture(scope="session")

@@ -10,6 +10,7 @@ sim/hip/hip_runtime.h.  The product never loads a simulator library: engine.py t
 PCLSEG_DEBUG=1 + PCLSEG_LIB, which this module sets for the test process, and "device" tensors are CPU tensors
 (the simulator's device memory is host memory) through the three seams engine.torch_device / stream_handle /
 on_device."""
+import ctypes
 import os
 import subprocess
 
@@ -20,6 +21,8 @@ TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asa
 
 def library(variant="1"):
   """Path of the simulator build `variant`, (re)built by make when a source is newer."""
+  if os.environ.get("PCLSEG_SIM_LIB"):      # a simulator library built elsewhere (A/B of two simulator builds)
+    return os.environ["PCLSEG_SIM_LIB"]
   target, name = TARGETS[variant]
   subprocess.check_call(["make", "-s", "-C", SIM_DIR, target])
   return os.path.join(SIM_DIR, "_build", name)
@@ -38,7 +41,28 @@ def activate(variant="1"):
   # every torch tensor is "device" memory, except the ones host_tensor() below handed out; NumPy arrays are host
   E.on_device = lambda x: hasattr(x, "data_ptr") and _host_range(x.data_ptr()) is None
   E.is_pinned = lambda x: bool(_host_range(x.data_ptr()))
+  # `tensor.cpu()` on a device tensor is a copy ordered after the work of torch's current stream (the null stream here), and
+  # torch.cuda.synchronize() waits for the device: in the simulator's lazy stream mode (HIPSIM_STREAMS=lazy) that is what makes
+  # the queued kernels run — the library itself must have made the caller's stream wait for its lane streams
+  lib = E.load_library()
+  if hasattr(lib, "hipsim_sync_stream"):
+    lib.hipsim_sync_stream.argtypes = [ctypes.c_void_p]
+    lib.hipsim_sync_stream.restype = None
+    lib.hipsim_sync_device.restype = None
+    orig_cpu = torch.Tensor.cpu
+
+    def cpu(self, *a, **k):
+      if E.on_device(self):
+        lib.hipsim_sync_stream(None)
+      return orig_cpu(self, *a, **k)
+    torch.Tensor.cpu = cpu
+    global sync_device
+    sync_device = lib.hipsim_sync_device
   return E
+
+
+def sync_device():
+  """torch.cuda.synchronize() of the simulated device (re-bound by activate())."""
 
 
 _HOST = []     # (first byte, one past the last, pinned?) of every tensor host_tensor() handed out; views of them count
