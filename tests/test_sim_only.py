@@ -99,3 +99,52 @@ def test_bench_line_and_its_legs_on_the_simulator():
   assert "predictions identical to the device-resident run: True" in out["host_boundary"]["note"]
   for row in out["parity_check"]:
     assert row["decided_identical"] and row["max_abs_logit_err_f16x3"] <= 1e-3 and row["max_abs_logit_err_f32"] <= 1e-3, row
+
+
+_LAZY_CHILD = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import conftest, simlib
+import torch
+import pclsegmentation_amd as P
+from pclsegmentation_amd import engine as E
+from pclsegmentation_amd.utils.synthetic import synthetic_scans
+lib = E.load_library()
+assert lib.hipsim_streams_lazy() == 2
+lib.hipsim_memcpy_async.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+lib.hipsim_memcpy_async.restype = None
+mc, model = P.load_model_config("squeezesegv2", "squeezesegv2")
+model.init_weights(4321)
+model.micro_batch = 2
+n, h, w = 7, 32, 240                      # 4 micro-batches over 3 lanes
+raw = synthetic_scans(n, h, w, mc.INPUT_MEAN, mc.INPUT_STD, 0.84, seed=21)
+eng = model.engine(h, w)
+ref = np.empty((n, h, w), np.int32)
+eng.forward_raw(raw, n, ref, None, None, None, mem=E.MEM_HOST)
+src = simlib.host_tensor((n, h, w, 5), torch.float32, True)      # page-locked: stays valid until the copy has run
+src.copy_(torch.from_numpy(raw))
+x = torch.zeros((n, h, w, 5), dtype=torch.float32)               # the "device" tensor, still empty
+preds = torch.full((n, h, w), -5, dtype=torch.int32)
+eng.set_stream(0)
+lib.hipsim_memcpy_async(x.data_ptr(), src.data_ptr(), x.numel() * 4, None)     # queued on the caller's stream, not yet run
+assert float(x.abs().sum()) == 0.0
+eng.forward_raw(x, n, preds, None, None, None, mem=E.MEM_DEVICE)               # queued behind it
+assert int((preds == -5).sum()) == preds.numel()                               # nothing has run
+got = preds.cpu().numpy()                                                      # = wait for the caller's stream
+print("IDENTICAL" if np.array_equal(got, ref) else "DIFFERENT %%d pixels" %% int((got != ref).sum()))
+"""
+
+
+def test_lanes_wait_for_what_the_callers_stream_has_queued(tmp_path):
+  """HIPSIM_STREAMS=lazy: nothing runs before something waits for it.  The caller queues an upload of the scans on ITS
+  stream and calls pclseg_forward_raw(MEM_DEVICE) right behind it; the engine's lane streams must wait for the caller's
+  stream as it stood at the call (ev_in) and the caller's stream for the lanes at the end (join_lanes).  Waiting for
+  the caller's stream alone must then produce the right predictions; a lane that did not wait would have read zeros."""
+  r = subprocess.run([sys.executable, "-c", _LAZY_CHILD % {"root": ROOT}], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                     env=dict(os.environ, HIPSIM_STREAMS="lazy"))
+  assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+  # control: with every hipStreamWaitEvent forgotten (fault injection in the simulator) the same program must come out wrong
+  r = subprocess.run([sys.executable, "-c", _LAZY_CHILD % {"root": ROOT}], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                     env=dict(os.environ, HIPSIM_STREAMS="lazy", HIPSIM_DROP_WAITS="1"))
+  assert "DIFFERENT" in r.stdout or r.returncode != 0, r.stdout[-1500:]
