@@ -29,11 +29,14 @@
 // fiber — the lanes of a wave share it, because on the hardware a wave is one instruction stream and its LDS / memory
 // operations are ordered by program order — and the only happens-before edges are the ones the hardware gives:
 // a workgroup barrier orders all waves of the block, a launch boundary orders everything, atomics are atomics.
-// TSan then reports an LDS location written by one wave and touched by another with no barrier in between — the validated
-// use (race_driver selftest: reported without the barrier, clean with it, clean for lanes of one wave).  A global
-// location touched by two blocks of one launch is reported in some runs only (the self-test's control shows it), so
-// the detector is NOT relied on for inter-block races.  The simulator's own state lives in functions TSan does not
-// instrument; the scheduler runs under the TSan context of the wave that yielded last.
+// TSan then reports an LDS location written by one wave and touched by another with no barrier in between, and a global
+// location touched by two blocks of one launch that ran on different workers (race_driver selftest holds the controls:
+// each seeded race reported, the same code with the barrier / with atomics clean, lanes of one wave clean).  In this
+// build blocks are dealt statically (block b to worker b mod N) and no block starts before every worker holds the job:
+// a worker returning to the pool's mutex after a short block would otherwise order that block before every worker that
+// starts later — real synchronisation of that run, which hid the inter-block control until it was removed.  The
+// simulator's own state lives in functions TSan does not instrument; the scheduler runs under the TSan context of the
+// wave that yielded last.
 //
 // MFMA arithmetic: v_mfma_f32_16x16x4_f32 is a float32 fmaf chain over k = 0..3 (what the hardware does, DESIGN.md
 // §3); v_mfma_f32_16x16x32_f16 multiplies exactly (an f16 x f16 product fits a float32) and accumulates with one
@@ -50,6 +53,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <cxxabi.h>
 #include <dlfcn.h>
@@ -489,6 +493,7 @@ struct Job {
   uint64_t total = 0;
   std::atomic<uint64_t> next{0};
   std::atomic<uint64_t> finished{0};
+  std::atomic<int> arrived{0};      // (race-detector build: workers that have picked the job up)
 };
 
 struct Pool {
@@ -533,9 +538,13 @@ struct Pool {
       }
       if (!j) continue;
       uint64_t done = 0;
-#if defined(HIPSIM_TSAN) && !defined(HIPSIM_DYNAMIC_DEAL)
-      // race detector: blocks are dealt statically, block b to worker b mod N — neighbouring blocks always run on
-      // different TSan threads (blocks that follow one another on ONE worker are ordered and could not be reported)
+#ifdef HIPSIM_TSAN
+      // race detector: every worker picks the job up BEFORE any block runs (a relaxed counter: no happens-before edge), and
+      // blocks are dealt statically, block b to worker b mod N.  Otherwise a worker that finishes a short block and goes back
+      // to the pool's mutex orders that block before the blocks of every worker that picks the job up after it — real
+      // synchronisation of THIS run, which hides a race between the two blocks (with short blocks: always).
+      j->arrived.fetch_add(1, std::memory_order_relaxed);
+      while (j->arrived.load(std::memory_order_relaxed) < nworkers) sched_yield();
       for (uint64_t b = (uint64_t)index; b < j->total; b += (uint64_t)nworkers) {
 #else
       for (;;) {

@@ -1,8 +1,9 @@
 // Race-detection driver of the functional simulator (test infrastructure; see sim/hip/hip_runtime.h "Race detection").
 // Built with -fsanitize=thread together with the engine sources: every wave is a ThreadSanitizer fiber, barriers and
 // launch boundaries are the only happens-before edges, so a report is an LDS location shared by two waves without a
-// barrier (the validated use: see the self-test) or a global location shared by two blocks of one launch (best effort:
-// the self-test's inter-block control is reported in some runs only, so the absence of such a report proves nothing).  Runs forward passes of the three networks (random
+// barrier, or a global location shared by two blocks of one launch that run on different workers (blocks are dealt
+// statically, block b to worker b mod HIPSIM_THREADS, and no block starts before every worker holds the job; run with
+// two coprime worker counts to pair every two blocks on different workers).  Runs forward passes of the three networks (random
 // weights: only the access pattern matters) through the C ABI, both arithmetic modes, and the stand-alone projection /
 // confusion-matrix operators.  Exit status 0 = no report (TSAN_OPTIONS=exitcode=66 otherwise).
 //   usage: race_driver [ssv2|dn21|dn53|ops ...]      (default: all four, small shapes)
@@ -68,10 +69,6 @@ static int run_selftest() {
   for (int i = 0; i < 5; ++i) {
     auto& r = row[i];
     const bool reported = r.after > r.before;
-    if (i == 3) {      // races BETWEEN blocks: ThreadSanitizer reports them in some runs and not in others here (not understood)
-      printf("selftest: %-40s %s (informational: inter-block detection is NOT relied on)\n", r.name, reported ? "REPORTED" : "not reported");
-      continue;
-    }
     printf("selftest: %-40s %s (%s)\n", r.name, reported ? "REPORTED" : "clean", reported == r.racy ? "as it must be" : "WRONG");
     bad += reported != r.racy;
   }

@@ -16,6 +16,8 @@ if SIM:      # simulator mode (tests/simlib.py): the same C program, linked with
 
 @pytest.fixture(scope="module")
 def consumer(tmp_path_factory):
+  if SIM in ("asan", "ubsan"):
+    pytest.skip("the sanitizer builds of the simulator need their runtime linked into the C program")
   if not os.path.isfile(os.path.join(LIBDIR, LIBNAME)):
     pytest.fail("libpclseg.so is not built (run `make`)")
   exe = str(tmp_path_factory.mktemp("c_abi") / "consumer")
