@@ -334,7 +334,13 @@ hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const 
 #define PCLSEG_GO(EPI_) \
   hipLaunchKernelGGL((conv_kernel<MTW, NTW, WN, HEAD, F16, EPI_, PAIR, NW>), grid, dim3(NW * 64), lds, s, a)
   if constexpr (HEAD) { PCLSEG_GO(0); }
-  else if constexpr (!F16) { PCLSEG_GO(4); }  // exact mode: one catch-all instantiation
+  else if constexpr (!F16) {   // exact mode: the two common epilogues get their own instantiation (the catch-all carries
+    switch (epi) {             // registers for every optional operand and spills 260-470 B in the 4-segment shapes)
+      case 0: PCLSEG_GO(0); break;
+      case 1: PCLSEG_GO(1); break;
+      default: PCLSEG_GO(4); break;
+    }
+  }
   else if constexpr (PAIR) {                  // FIRE expand pairs: plain, + skip add, + fused skip branch
     switch (epi) {
       case 0: PCLSEG_GO(0); break;
