@@ -8,6 +8,7 @@
 // confusion-matrix operators.  Exit status 0 = no report (TSAN_OPTIONS=exitcode=66 otherwise).
 //   usage: race_driver [ssv2|dn21|dn53|ops ...]      (default: all four, small shapes)
 //          race_driver full                         the three benchmark workloads at full size
+//          race_driver threads                      two host threads with a handle each (thread-safety of the library's globals)
 //          race_driver selftest                     positive and negative controls of the detector itself
 #include "../pclsegmentation_amd/csrc/pclseg_api.hip"      // one translation unit: the engine, then the driver
 
@@ -96,7 +97,7 @@ static int run_selftest() {
   return bad ? 3 : 0;
 }
 
-static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static thread_local uint64_t g_rng = 0x9E3779B97F4A7C15ull;
 static float urand() {
   g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17;
   return (float)((g_rng >> 40) / 16777216.0);
@@ -183,6 +184,11 @@ int main(int argc, char** argv) {
     run_net("Darknet-53 f32", PCLSEG_ARCH_DARKNET53, 16, 64, 20, 2, PCLSEG_FLAG_EXACT_F32);
   }
   if (want("ops")) run_ops();
+  if (want("threads") && !what.empty()) {      // two host threads, a handle each, at the same time: the library's process-wide state
+    std::thread t1([] { run_net("host thread 1: SqueezeSegV2", PCLSEG_ARCH_SQUEEZESEGV2, 32, 240, 11, 2, 0); });
+    std::thread t2([] { run_net("host thread 2: Darknet-21", PCLSEG_ARCH_DARKNET21, 16, 64, 20, 2, PCLSEG_FLAG_RANGE_FALLBACK); });
+    t1.join(); t2.join();
+  }
   if (!what.empty() && what[0] == "full") {   // the benchmark workloads at their full size (BASELINE.json configs[1], [4], [2]); slow
     run_net("SqueezeSegV2 f16x3 full", PCLSEG_ARCH_SQUEEZESEGV2, 64, 2048, 20, 4, 0);
     run_net("Darknet-21 f16x3 full", PCLSEG_ARCH_DARKNET21, 32, 1024, 20, 2, 0);
