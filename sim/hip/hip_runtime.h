@@ -117,6 +117,36 @@ struct Registry {
   }
 };
 
+// ---- footprint of a launch in device memory (make -C sim traffic; -DHIPSIM_TRAFFIC + -fsanitize-coverage=trace-loads,trace-stores)
+// Every load and store of kernel code calls back with its address; accesses to device allocations set one bit per 64-byte
+// line in a read and a write bitmap.  Per launch: the lines read / written at least once (what a launch must move when
+// every line is fetched once — its compulsory traffic) and the bytes requested (what the caches see).  No cache model.
+#ifdef HIPSIM_TRAFFIC
+#define HIPSIM_NO_COV __attribute__((no_sanitize("coverage")))
+struct TrafficRegion { uintptr_t lo, hi; std::vector<uint64_t>* rd; std::vector<uint64_t>* wr; };
+struct Traffic {
+  std::vector<TrafficRegion> regions;          // sorted, rebuilt when the set of device allocations changes
+  std::atomic<uint64_t> req_rd{0}, req_wr{0};
+  bool dirty = true;
+  static Traffic& get() { static Traffic* t = new Traffic(); return *t; }
+};
+inline thread_local bool tl_in_kernel = false;
+HIPSIM_NO_COV inline void traffic_access(uintptr_t a, unsigned size, bool write) {
+  if (!tl_in_kernel) return;
+  Traffic& t = Traffic::get();
+  size_t lo = 0, hi = t.regions.size();
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (t.regions[mid].hi <= a) lo = mid + 1; else hi = mid; }
+  if (lo == t.regions.size() || a < t.regions[lo].lo) return;      // LDS, stack, host memory
+  const TrafficRegion& r = t.regions[lo];
+  std::vector<uint64_t>& bm = write ? *r.wr : *r.rd;
+  for (uintptr_t line = (a - r.lo) >> 6, last = (a + size - 1 - r.lo) >> 6; line <= last; ++line)
+    __atomic_fetch_or(&bm[line >> 6], 1ull << (line & 63), __ATOMIC_RELAXED);
+  (write ? t.req_wr : t.req_rd).fetch_add(size, std::memory_order_relaxed);
+}
+#else
+#define HIPSIM_NO_COV
+#endif
+
 inline hipError_t alloc(void** p, size_t n, bool dev) {
   Registry& r = Registry::get();
   std::lock_guard<std::mutex> lk(r.mu);
@@ -125,6 +155,9 @@ inline hipError_t alloc(void** p, size_t n, bool dev) {
   if (posix_memalign(&q, 4096, n ? n : 1) != 0) return hipErrorOutOfMemory;
   memset(q, 0xFF, n);   // fresh memory is garbage on the device too; NaN-fill makes a read of it visible
   (dev ? r.device : r.pinned)[(uintptr_t)q] = n ? n : 1;
+#ifdef HIPSIM_TRAFFIC
+  if (dev) Traffic::get().dirty = true;
+#endif
   if (dev) r.device_bytes += n;
   *p = q;
   return hipSuccess;
@@ -138,11 +171,31 @@ inline hipError_t release(void* p, bool dev) {
   if (it == m.end()) return hipErrorInvalidValue;
   if (dev) r.device_bytes -= it->second;
   m.erase(it);
+#ifdef HIPSIM_TRAFFIC
+  if (dev) Traffic::get().dirty = true;
+#endif
   free(p);
   return hipSuccess;
 }
 
 }  // namespace hipsim
+
+#ifdef HIPSIM_TRAFFIC
+extern "C" {
+HIPSIM_NO_COV void __sanitizer_cov_load1(uint8_t* a) { hipsim::traffic_access((uintptr_t)a, 1, false); }
+HIPSIM_NO_COV void __sanitizer_cov_load2(uint16_t* a) { hipsim::traffic_access((uintptr_t)a, 2, false); }
+HIPSIM_NO_COV void __sanitizer_cov_load4(uint32_t* a) { hipsim::traffic_access((uintptr_t)a, 4, false); }
+HIPSIM_NO_COV void __sanitizer_cov_load8(uint64_t* a) { hipsim::traffic_access((uintptr_t)a, 8, false); }
+HIPSIM_NO_COV void __sanitizer_cov_load16(__uint128_t* a) { hipsim::traffic_access((uintptr_t)a, 16, false); }
+HIPSIM_NO_COV void __sanitizer_cov_store1(uint8_t* a) { hipsim::traffic_access((uintptr_t)a, 1, true); }
+HIPSIM_NO_COV void __sanitizer_cov_store2(uint16_t* a) { hipsim::traffic_access((uintptr_t)a, 2, true); }
+HIPSIM_NO_COV void __sanitizer_cov_store4(uint32_t* a) { hipsim::traffic_access((uintptr_t)a, 4, true); }
+HIPSIM_NO_COV void __sanitizer_cov_store8(uint64_t* a) { hipsim::traffic_access((uintptr_t)a, 8, true); }
+HIPSIM_NO_COV void __sanitizer_cov_store16(__uint128_t* a) { hipsim::traffic_access((uintptr_t)a, 16, true); }
+HIPSIM_NO_COV void __sanitizer_cov_8bit_counters_init(char*, char*) {}
+HIPSIM_NO_COV void __sanitizer_cov_pcs_init(const uintptr_t*, const uintptr_t*) {}
+}
+#endif
 
 namespace hipsim {
 inline thread_local hipError_t last_error = hipSuccess;      // sticky until read, as hipGetLastError
@@ -449,7 +502,13 @@ HIPSIM_NO_TSAN inline void run_block(Worker& w, const dim3 grid, const dim3 bloc
 #ifdef HIPSIM_TSAN
     if (w.tsan_cur != w.tsan_wave[t >> 6]) { w.tsan_cur = w.tsan_wave[t >> 6]; __tsan_switch_to_fiber(w.tsan_cur, __tsan_switch_to_fiber_no_sync); }
 #endif
+#ifdef HIPSIM_TRAFFIC
+    tl_in_kernel = true;
+#endif
     hipsim_switch(&w.sched_sp, f.sp);
+#ifdef HIPSIM_TRAFFIC
+    tl_in_kernel = false;
+#endif
 #ifdef HIPSIM_ASAN
     __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
 #endif
@@ -603,6 +662,49 @@ inline void trace_launch(const void* kernel, dim3 g, dim3 b, size_t lds) {
 
 void enqueue(hipStream_t stream, std::function<void()> fn);      // (stream model, below)
 
+#ifdef HIPSIM_TRAFFIC
+HIPSIM_NO_COV inline void traffic_begin() {
+  Traffic& t = Traffic::get();
+  Registry& r = Registry::get();
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (!t.dirty) return;
+  std::map<uintptr_t, TrafficRegion> old;
+  for (auto& x : t.regions) old[x.lo] = x;
+  t.regions.clear();
+  for (auto& kv : r.device) {
+    TrafficRegion x{kv.first, kv.first + kv.second, nullptr, nullptr};
+    auto it = old.find(kv.first);
+    const size_t words = ((kv.second + 63) / 64 + 63) / 64;
+    if (it != old.end() && it->second.hi == x.hi) { x.rd = it->second.rd; x.wr = it->second.wr; old.erase(it); }
+    else { x.rd = new std::vector<uint64_t>(words, 0); x.wr = new std::vector<uint64_t>(words, 0); }
+    t.regions.push_back(x);
+  }
+  for (auto& kv : old) { delete kv.second.rd; delete kv.second.wr; }
+  t.dirty = false;
+}
+HIPSIM_NO_COV inline void traffic_end(const void* kernel, dim3 g) {
+  Traffic& t = Traffic::get();
+  uint64_t rd = 0, wr = 0;
+  for (auto& x : t.regions) {
+    for (auto& w : *x.rd) { rd += (uint64_t)__builtin_popcountll(w); w = 0; }
+    for (auto& w : *x.wr) { wr += (uint64_t)__builtin_popcountll(w); w = 0; }
+  }
+  const uint64_t qr = t.req_rd.exchange(0), qw = t.req_wr.exchange(0);
+  static const char* path = getenv("HIPSIM_TRAFFIC_LOG");
+  if (!path || !*path) return;
+  Dl_info info;
+  const char* sym = (dladdr(kernel, &info) && info.dli_sname) ? info.dli_sname : "?";
+  int status = 0;
+  char* dem = abi::__cxa_demangle(sym, nullptr, nullptr, &status);
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s\t%u\t%llu\t%llu\t%llu\t%llu\n", status == 0 && dem ? dem : sym, g.x * g.y * g.z, (unsigned long long)rd * 64,
+            (unsigned long long)wr * 64, (unsigned long long)qr, (unsigned long long)qw);
+    fclose(f);
+  }
+  free(dem);
+}
+#endif
+
 template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t stream, const void* kernel, F&& f) {
   trace_launch(kernel, g, b, lds);
   if (lds > 64 * 1024) {
@@ -617,7 +719,11 @@ template <class F> inline void launch(dim3 g, dim3 b, size_t lds, hipStream_t st
   if (b.x * b.y * b.z == 0 || b.x * b.y * b.z > 1024 || g.x == 0 || g.y == 0 || g.z == 0) { last_error = hipErrorInvalidValue; return; }
   // the kernel's arguments are captured BY VALUE: in the lazy stream mode the grid runs when something waits for it
   std::function<void()> body(std::forward<F>(f));
+#ifdef HIPSIM_TRAFFIC
+  enqueue(stream, [g, b, lds, body, kernel] { traffic_begin(); Pool::get().launch(g, b, lds, body); traffic_end(kernel, g); });
+#else
   enqueue(stream, [g, b, lds, body] { Pool::get().launch(g, b, lds, body); });
+#endif
 }
 
 // ---- streams and events ------------------------------------------------------------------------------------------

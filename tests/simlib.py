@@ -16,7 +16,8 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_DIR = os.path.join(ROOT, "sim")
-TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asan.so"), "ubsan": ("ubsan", "libpclseg_sim_ubsan.so")}
+TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asan.so"), "ubsan": ("ubsan", "libpclseg_sim_ubsan.so"),
+           "traffic": ("traffic", "libpclseg_sim_traffic.so")}
 
 
 def library(variant="1"):
