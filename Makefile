@@ -18,7 +18,13 @@ all: $(LIB)
 $(LIB): $(SRCS)
 	$(call hipbuild,$@,$(EXTRA))
 
-# debug build with in-kernel phase timestamps (PCLSEG_STAMP=<layer>, loaded through PCLSEG_DEBUG_LIB)
+# the candidate kernel variants of pclseg_kernels.h (never run on an MI355X; NOT in the shipped library): the
+# hardware A/B of scripts/gpu_step2.sh loads this one through PCLSEG_DEBUG=1 PCLSEG_LIB=build/libpclseg_cand.so
+candidates: $(SRCS)
+	@mkdir -p build
+	$(call hipbuild,build/libpclseg_cand.so,-DPCLSEG_CAND $(EXTRA))
+
+# debug build with in-kernel phase timestamps (PCLSEG_STAMP=<layer>; loaded with PCLSEG_DEBUG=1 PCLSEG_LIB=build/libpclseg_stamps.so)
 stamps: $(SRCS)
 	@mkdir -p build
 	$(call hipbuild,build/libpclseg_stamps.so,-DPCLSEG_WITH_STAMPS $(EXTRA))
@@ -38,4 +44,4 @@ clean:
 	rm -f $(LIB) pclsegmentation_amd/libpclseg_*.so
 	rm -rf build sim/_build
 
-.PHONY: all clean stamps tuning variant
+.PHONY: all clean stamps tuning variant candidates

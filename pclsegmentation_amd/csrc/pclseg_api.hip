@@ -334,6 +334,7 @@ hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const 
 #define PCLSEG_GO(EPI_) \
   hipLaunchKernelGGL((conv_kernel<MTW, NTW, WN, HEAD, F16, EPI_, PAIR, NW>), grid, dim3(NW * 64), lds, s, a)
   if constexpr (HEAD) { PCLSEG_GO(0); }
+#ifdef PCLSEG_CAND_EXACTEPI
   else if constexpr (!F16) {   // exact mode: the two common epilogues get their own instantiation (the catch-all carries
     switch (epi) {             // registers for every optional operand and spills 260-470 B in the 4-segment shapes)
       case 0: PCLSEG_GO(0); break;
@@ -341,6 +342,9 @@ hipError_t launch_conv_epi(int epi, dim3 grid, size_t lds, hipStream_t s, const 
       default: PCLSEG_GO(4); break;
     }
   }
+#else
+  else if constexpr (!F16) { PCLSEG_GO(4); }  // exact mode: one catch-all instantiation
+#endif
   else if constexpr (PAIR) {                  // FIRE expand pairs: plain, + skip add, + fused skip branch
     switch (epi) {
       case 0: PCLSEG_GO(0); break;
@@ -424,6 +428,7 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
+#ifdef PCLSEG_CAND_GEOM2
   // fire4 (32 -> 128 + 128 -> 32, 4 x 16-pixel tiles, WN = 8): conv_kernel GEOM 2
   if (op.mtw == 4 && op.ntw == 1 && op.wn == 8 && a.fsq_q == 32 && epi == 0 && op.cin_t == 32 && a.in_s16 && a.PW == 18 && a.PH == 6 &&
       op.ck16 >= 32 && !op.up_fused) {
@@ -432,6 +437,7 @@ hipError_t launch_conv_fsq(const Op& op, int epi, dim3 grid, size_t lds, hipStre
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
+#endif
 #define PCLSEG_X(M_, N_, W_, Q_, E_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && a.fsq_q == Q_ * 16 && epi == E_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_>; \
@@ -459,6 +465,7 @@ hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStrea
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
+#ifdef PCLSEG_CAND_GEOM2
   // fire11 (32-channel up-convolved patch, 8 x 16-pixel tiles, WN = 4): conv_kernel GEOM 2
   if (op.mtw == 4 && op.ntw == 1 && op.wn == 4 && op.nw == 8 && nq == 1 && epi == 1 && op.cin_t == 32 && a.PW == 18 && a.PH == 10 &&
       op.ck16 >= 32) {   // (one chunk: 40 halfs per staged pixel and plane)
@@ -467,6 +474,7 @@ hipError_t launch_conv_up(const Op& op, int epi, dim3 grid, size_t lds, hipStrea
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, s, a);
     return hipGetLastError();
   }
+#endif
 #define PCLSEG_X(M_, N_, W_, Q_, E_, U_) \
   if (op.mtw == M_ && op.ntw == N_ && op.wn == W_ && op.nw == 8 && nq == Q_ && epi == E_ && op.cin_t == 16 * U_) { \
     auto kfn = conv_kernel<M_, N_, W_, false, true, E_, true, 8, Q_, U_>; \
@@ -532,6 +540,7 @@ struct StampDump {
 };
 #endif
 
+#ifdef PCLSEG_CAND_WIDE
 // Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1, float32 input, no fused operands) run on
 // conv1x1_wide_kernel: launch_conv and pclseg_plan_ops both ask here, and tests/test_sim_only.py compares the plan
 // with the launches the simulator sees.
@@ -544,6 +553,7 @@ void wide_1x1_geom(const Op& op, int* nt, int* ny) {
   *nt = op.sub[0].nctp % 16 == 0 ? 2 : 1;
   *ny = op.sub[0].nctp / (8 * *nt);
 }
+#endif
 
 // Fill the geometry of `a` (tensor pointers already set) from `op` and launch.
 // w32 / w16 / bias are the bases the sub-op offsets are relative to.
@@ -654,7 +664,9 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
   if (op.fsq_fused) {   // the partial-sum slab [8 waves][mtw*16 px][Q] float32 reuses the patch's LDS
     if (exact) return hipErrorInvalidValue;
     size_t slab = (size_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * sizeof(float);   // rows padded by 4 floats
+#ifdef PCLSEG_CAND_SLAB
     if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (size_t)8 * op.mtw * 16 * (2 * 16 + 4) * sizeof(float);   // two passes (conv_kernel NPASS)
+#endif
     lds = std::max(lds, slab);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
   } else if (lds > 64 * 1024) return hipErrorInvalidValue;
@@ -675,6 +687,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
     static const int gm = tune_env("PCLSEG_GROUP_MAJOR", -1);
     a.group_major = gm >= 0 ? gm : (ny > 1 && wbytes > 2.0 * 1024 * 1024);
   }
+#ifdef PCLSEG_CAND_WIDE
   // Darknet's wide 1x1 layers (BasicBlock / decoder-block conv1): the software-pipelined GEMM kernel
   if (!exact && w16 && op_is_wide_1x1(op, a.in_s16 != 0, a.res1 || a.res2, a.skx != nullptr)) {
     static const int wide_on = tune_env("PCLSEG_WIDE1X1", 1);
@@ -695,6 +708,7 @@ hipError_t launch_conv(const Op& op_in, int N, int H, int Win, ConvArgs a, const
       return hipGetLastError();
     }
   }
+#endif
   dim3 grid((unsigned)(a.N * a.tilesH * a.tilesW * ny));
 #ifdef PCLSEG_WITH_STAMPS
   StampDump stamp_dump(op.name(), &a.stamps, grid, s);   // debug build: PCLSEG_STAMP=<layer name> prints its phase split
@@ -1616,13 +1630,16 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
       same_pad(Wc, op.pkw, op.sw, &wo2, &pl2);
       const int wconv = op.ow_mul == 2 ? Wc : wo2;
       threads = op.nw * 64;
+#ifdef PCLSEG_CAND_WIDE
       if (!direct && op_is_wide_1x1(op, g.tensors[op.in].fmt == FMT_S16, op.res1 >= 0 || op.res2 >= 0, op.sk_in >= 0)) {
         int nt, ny_w;
         wide_1x1_geom(op, &nt, &ny_w);
         lds = kW1Lds;
         threads = 512;
         blocks = (((int64_t)ti.H * ti.W + kW1Px - 1) / kW1Px) * ny_w;
-      } else if (direct) {
+      } else
+#endif
+      if (direct) {
         const bool splitk = op.cin_t >= 256 && op.sub[0].nctp >= 3;
         lds = splitk ? (int64_t)4 * 2 * op.sub[0].nctp * 1024 : 0;
         const int px = splitk ? 32 : 4 * (op.sub[0].nctp == 4 ? 1 : 2) * 16;
@@ -1633,7 +1650,9 @@ int pclseg_plan_ops(const pclseg_desc* desc, char* buf, size_t cap) try {
         if (op.up_fused) lds = ((lds + 15) & ~(int64_t)15) + (int64_t)t.PH * (t.PW / 2 + 1) * (2 * op.cin_t + kPadF16) * 2;
         if (op.fsq_fused) {
           int64_t slab = (int64_t)8 * op.mtw * 16 * (op.fsq.nctp * 16 + 4) * 4;
+#ifdef PCLSEG_CAND_SLAB
           if (op.fsq.nctp == 4 && slab > 96 * 1024) slab = (int64_t)8 * op.mtw * 16 * (2 * 16 + 4) * 4;
+#endif
           lds = std::max<int64_t>(lds, slab);
         }
         int ny = 0;
@@ -1658,6 +1677,19 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) try {
   HandleGuard hg{h};            // releases the half-built handle on every early exit, thrown or returned
   int rc = build_graph(desc, &h->g);
   if (rc) return fail(nullptr, rc, h->g.error);
+#ifndef PCLSEG_TUNING
+  // The shipped dispatch tables hold the fused skip-branch epilogue (nets/SqueezeSegV2.py:293,319) for merged expand
+  // pairs on 8-wave blocks only (launch_conv: `pair`; launch_conv_epi has no epi 3/4 outside a pair).  A plan that
+  // demotes such a pair (op_geometry: patch in more than one chunk; pair_cfg_ok) is refused HERE, with a message,
+  // instead of surfacing as hipErrorInvalidValue at the first forward call.  (Exact mode has a catch-all epilogue.)
+  if (!(desc->flags & PCLSEG_FLAG_EXACT_F32))
+    for (const Op& op : h->g.ops)
+      if (op.kind == OP_CONV && op.sk_in >= 0 && !op.head_fused &&
+          !(op.pair && pair_cfg_ok(op) && op.nw == 8 && op.ntw == 1 && op.res1 < 0 && op.res2 < 0))
+        return fail(nullptr, PCLSEG_ERR_BAD_SHAPE,
+                    fmt("layer %s: the fused skip branch needs a merged expand pair on 8-wave blocks; this plan gives "
+                        "(pair %d, waves %d, cout tiles per wave %d)", op.name().c_str(), (int)op.pair, op.nw, op.ntw));
+#endif
   h->device = desc->device;
   h->host_w.resize(h->g.weights.size());
   h->is_set.assign(h->g.weights.size(), 0);
@@ -1712,6 +1744,8 @@ int pclseg_create(const pclseg_desc* desc, pclseg_handle** out) try {
   if (e != hipSuccess)
     return bail(e == hipErrorOutOfMemory ? PCLSEG_ERR_OOM : PCLSEG_ERR_HIP,
                 fmt("hipMalloc(parameters): %s", hipGetErrorString(e)));
+  // a dead handle's exception-barrier text must not speak for a new handle the allocator placed at the same address
+  if (g_static_handle == h) { g_static_error = nullptr; g_static_handle = nullptr; }
   hg.h = nullptr;
   *out = h;
   return PCLSEG_OK;
@@ -1743,6 +1777,7 @@ int pclseg_destroy(pclseg_handle* h) try {
   void* bufs[] = {h->d_w32, h->d_w16, h->d_bias, h->d_range};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
+  if (g_static_handle == h) { g_static_error = nullptr; g_static_handle = nullptr; }
   delete h;
   return PCLSEG_OK;
 } PCLSEG_CATCH(h)

@@ -29,6 +29,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// CANDIDATE kernel variants: written in rounds 4-5, bit-identical to the shipped code paths on the functional simulator,
+// but never run on an MI355X — the shipped library (plain `make`) does not contain them: its device kernels are
+// instruction-identical to the set round 3 verified and measured on hardware (scripts/kernel_isa_diff.py ad2e081).
+// `make candidates` (-DPCLSEG_CAND) builds build/libpclseg_cand.so with all of them for the hardware A/B of
+// scripts/gpu_step2.sh; each has its own switch for per-component builds (make variant NAME=tail EXTRA=-DPCLSEG_CAND_TAIL).
+// A candidate moves out of this block (and its #else branch is deleted) only when it is bit-identical AND not slower
+// on the device.
+#ifdef PCLSEG_CAND
+#define PCLSEG_CAND_TAIL 1   // fire_head_kernel: batched up-convolution, prefetched epilogue operands, pipelined conv14 sweep
+#define PCLSEG_CAND_CAM 1    // cam_kernel SQ: fused-squeeze fragments requested one gate pass ahead
+#define PCLSEG_CAND_SLAB 1   // conv_kernel FSQ: fire8/9's partial-sum slab in two passes (70 KB instead of 136 KB)
+#define PCLSEG_CAND_WIDE 1   // conv1x1_wide_kernel for Darknet's wide 1x1 layers
+#define PCLSEG_CAND_KPIPE 1  // conv_kernel GEOM 1, fire8/9's 64-pixel merged pairs: fragment reads one K-step ahead of the MFMAs
+#define PCLSEG_CAND_GEOM2 1  // conv_kernel GEOM 2: compile-time geometry K loop for the 32-channel merged pairs (fire4, fire11)
+#define PCLSEG_CAND_EXACTEPI 1  // exact-float32 mode: own instantiations of the plain and the residual epilogue (pclseg_api.hip)
+#endif
+
 namespace pclseg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -776,6 +793,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
     };
 
     auto kloop = [&](const ConvSub& K, const int chunk, const int ck8, const _Float16* const sm) {   // (sm: the LDS buffer to read)
+#ifdef PCLSEG_CAND_GEOM2
       // GEOM = 2 (round 4): the same compile-time geometry for the merged pairs with a 32-channel patch — fire4 (64-pixel
       // tiles, WN = 8) and fire11 (128-pixel tiles, WN = 4: wave (wm, wn) owns tile rows 4 wm .. 4 wm + 3) — whose K loop is
       // 9 K-steps of 12 MFMAs: one step = one tap (lane group g = channels 8 g ..), every fragment address one per-lane
@@ -825,6 +843,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
         }
         return;
       }
+#endif
       if constexpr (GEOM == 1) {
         static_assert((MTW == 8 || MTW == 4) && WN == 8 && NW == 8, "GEOM 1: MTW x 16-pixel tiles (one segment per tile row) of the 8-wave blocks");
         constexpr int kPW = 18, kCS = 72, kPlane = (MTW + 2) * 18 * 72;   // (host-checked against a.PW / CSh / plane)
@@ -856,6 +875,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
             __builtin_amdgcn_sched_barrier(0);
           }
         };
+#ifdef PCLSEG_CAND_KPIPE
         // (round 4) the merged pairs' 64-pixel blocks (fire8/9: one block per CU, two waves per SIMD, 186
         // registers): hipcc emits a K-step as `4 reads, wait, 12 NTW MFMAs` — every step starts with an LDS round
         // trip.  Here the 8 fragment reads of step st + 1 are issued BEFORE the MFMAs of step st (two register
@@ -917,6 +937,7 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
           }
           return;
         }
+#endif
         if (!PAIR || K.nkh == 3) {   // 3x3: 18 K-steps, tap s / 2 (single convs are always 3x3 here: host-checked)
           constexpr int kSteps = 18;
           const _Float16* wb = K.w16 + ((size_t)(chunk * kSteps) * K.nctp + ct0) * 1024;   // scalar
@@ -1123,8 +1144,9 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
         // Slab rows are padded by 4 floats: with Q a multiple of 16 the 8 consecutive pixels one
         // ds_write_b128 lane group covers would otherwise all start in the same bank (rows 64..256 B
         // apart: an 8- to 16-way conflict that made this phase 29 % of the block).
+#ifdef PCLSEG_CAND_SLAB
         constexpr int Q = FSQ * 16, PXW = MTW * 16;
-        // the 136 KB slab of fire8/9 goes through LDS in TWO passes of half the squeeze
+        // (candidate, -DPCLSEG_CAND) the 136 KB slab of fire8/9 goes through LDS in TWO passes of half the squeeze
         // tiles: 70 KB per block, so that a block of another lane's memory-bound kernel can share the CU
         // (profiles/r04_ssv2_3lane_counters.txt: a 136 KB block is placed only on an EMPTY CU)
         constexpr int NPASS = (FSQ == 4 && NW * PXW * (Q + 4) * 4 > 96 * 1024) ? 2 : 1;
@@ -1165,6 +1187,41 @@ __global__ __launch_bounds__((NW + LW) * 64, LW ? 3 : ((NW == 8 && !OCC128) ? 2 
           }
         }
       }
+#else
+        constexpr int Q = FSQ * 16, PXW = MTW * 16, QS = Q + 4;
+        float* slab = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int qt = 0; qt < FSQ; ++qt)
+            *reinterpret_cast<f32x4*>(slab + ((size_t)(wave * PXW + m * 16 + p) * QS + qt * 16 + 4 * g)) = acc2[m][qt];
+        __syncthreads();
+        constexpr int WMc = NW / WN, QQ = Q / 4;
+        for (int idx = tid; idx < WMc * PXW * QQ; idx += kThreads) {
+          const int px = idx / QQ, qq = idx - px * QQ;
+          const int wmi = px / PXW, pl = px - wmi * PXW;
+          f32x4 sum = *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN) * PXW + pl) * QS + qq * 4));
+#pragma unroll
+          for (int w = 1; w < WN; ++w)
+            sum += *reinterpret_cast<const f32x4*>(slab + ((size_t)((wmi * WN + w) * PXW + pl) * QS + qq * 4));
+          sum = fma4(sum, a.fsq_bias[Q + ((qq * 4) & ~15)], *reinterpret_cast<const f32x4*>(a.fsq_bias + qq * 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.0f);
+          const int seg = wmi * MTW + (pl >> 4), pp = pl & 15;
+          const int sr = seg / a.SEGW;
+          const int oh = h0 + sr, j = w0 + (seg - sr * a.SEGW) * 16 + pp;
+          if (oh < a.H && j < a.Wconv) {
+            f16x4 hi, lo;
+            split4(sum, hi, lo);
+            vmax = absmax4(vmax, sum);
+            _Float16* o16 = reinterpret_cast<_Float16*>(a.out) + (((size_t)n * a.H + oh) * a.Wout + j) * (size_t)(2 * Q) + qq * 4;
+            *reinterpret_cast<f16x4*>(o16) = hi;
+            *reinterpret_cast<f16x4*>(o16 + Q) = lo;
+          }
+        }
+      }
+#endif
     } else if constexpr (LW > 0) {
       // two LDS buffers; loaders fill buffer (c + 1) & 1 while the compute waves read buffer c & 1.  Barrier
       // #c (c = 0 .. nchunks - 1) is passed by the loaders after staging chunk c and by the compute waves
@@ -1411,6 +1468,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   // output column w = 2j + parity reads x[j - 1 + parity] (tap 0) and x[j + parity] (tap 1); U column pc
   // is image column w0 - 2 + pc (w0 - 2 is even, so pc has the parity of w)
   {
+#ifdef PCLSEG_CAND_TAIL
     constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16, NU = (UNITS + 1) / 2, NB = 2;
     static_assert(NU % NB == 0, "units per wave in batches of NB");
     // (the wave's NU units in batches of NB: the batch's fragment reads, then its NB independent 3-MFMA chains,
@@ -1456,6 +1514,39 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
       }
     }
   }
+#else
+    constexpr int PER = kFhUH * (kFhUW / 2), UNITS = (PER + 15) / 16;
+#pragma nounroll
+    for (int u0 = 0; u0 < UNITS; u0 += 2) {
+      const int u = u0 + (wave >> 1);
+      const int l = u * 16 + p;
+      const int lc = l < PER ? l : PER - 1;
+      const int pr = lc / (kFhUW / 2), k2 = lc - pr * (kFhUW / 2);
+      const int pc = 2 * k2 + parity;
+      const int h = h0 - 2 + pr, w = w0 - 2 + pc;
+      const bool pv = h >= 0 && h < a.H && w >= 0 && w < a.W;
+      const int tap = g >> 1, c8 = g & 1;
+      const _Float16* sp = S + (pr * kFhSW + k2 + parity + tap) * kFhCSU + c8 * 8;
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(sp);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(sp + 16);
+      f32x4 au = (f32x4){0.f, 0.f, 0.f, 0.f};
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwl, xh, au, 0, 0, 0);
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xl, au, 0, 0, 0);
+      au = __builtin_amdgcn_mfma_f32_16x16x32_f16(uwh, xh, au, 0, 0, 0);
+      {   // (lanes past the last pixel were clamped onto it: they compute and store ITS value again — no branch)
+        f32x4 v = fma4(au, ui, ub);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pv ? fmaxf(v[e], 0.0f) : 0.0f;
+        vmax = absmax4(vmax, v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        _Float16* d = U + (pr * kFhUW + pc) * kFhCSU + g * 4;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 16) = lo;
+      }
+    }
+  }
+#endif
   lds_barrier();   // U complete (and every wave is done reading S: F may be overwritten)
   stamp(2);
 
@@ -1535,6 +1626,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     }
     stamp(4);
     asm volatile("" ::: "memory");
+#ifdef PCLSEG_CAND_TAIL
     // (round 4) the epilogue's own operands — the skip branch's fragments and the two bias quads of each cout tile —
     // are requested HERE, together, into the registers the expand fragments have just left; they were fetched inside
     // the per-tile loop right in front of their use: four L2 round trips in a row per block
@@ -1592,6 +1684,61 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     asm volatile("" ::: "memory");
     load_hw(1); load_hw(2); load_hw(3); load_hw(4);
   }
+#else
+    load_hw(0); load_hw(1); load_hw(2);   // (the last two steps' follow the epilogue: register budget)
+    // bias + ReLU, + skip branch (nets/SqueezeSegV2.py:293,319), zero outside the image, split -> F.
+    // The skip branch (1x1 conv of the 8-channel input) runs on the matrix cores too: K = 8 is one quarter
+    // of a 32-deep step (lane group 0), three MFMAs per (segment, cout tile) instead of 32 FMAs + 9 LDS reads —
+    // this kernel is bound by vector-instruction issue, the matrix pipe has room.
+    f16x8 sxh[3], sxl[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = g == 0 ? sx0[m][e] : 0.0f, x1 = g == 0 ? sx1[m][e] : 0.0f;
+        const _Float16 h0v = (_Float16)x0, h1v = (_Float16)x1;
+        sxh[m][e] = h0v; sxh[m][4 + e] = h1v;
+        sxl[m][e] = (_Float16)(x0 - (float)h0v); sxl[m][4 + e] = (_Float16)(x1 - (float)h1v);
+      }
+      vmax = absmax4(absmax4(vmax, sx0[m]), sx1[m]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* bb = t < 2 ? a.e1_bias : a.e3_bias;
+      const int tt = t & 1, co = t * 16 + g * 4;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + tt * 16 + g * 4);
+      const float iv = sload(bb + 32 + tt * 16);
+      const f16x8 kwh = *reinterpret_cast<const f16x8*>(a.sk_w16 + t * 1024 + lane8);
+      const f16x8 kwl = *reinterpret_cast<const f16x8*>(a.sk_w16 + t * 1024 + 512 + lane8);
+      const f32x4 kb = *reinterpret_cast<const f32x4*>(a.sk_bias + t * 16 + g * 4);
+      const float ki = sload(a.sk_bias + 64 + t * 16);
+      f32x4 z[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        z[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwl, sxh[m], z[m], 0, 0, 0);
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwh, sxl[m], z[m], 0, 0, 0);
+        z[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kwh, sxh[m], z[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        f32x4 v = fma4(acc[m][t], iv, bv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        v += fma4(z[m], ki, kb);
+        if (!fimg[m]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        vmax = absmax4(vmax, v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        _Float16* d = F + foff[m] + co;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 64) = lo;
+      }
+    }
+    asm volatile("" ::: "memory");
+    load_hw(3); load_hw(4);
+  }
+#endif
   lds_barrier();
   stamp(5);
 
@@ -1608,6 +1755,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
 #pragma unroll
       for (int t = 0; t < NCT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fbase = p * kFhCSF + g * 8;
+#ifdef PCLSEG_CAND_TAIL
     // Software-pipelined over the (K-step, row) groups: the two fragment reads of group k + 1 are issued BEFORE the
     // six MFMAs of group k and land while those run (hipcc, left alone, emitted `2 reads, wait, 6 MFMAs` per
     // group: ~100 cycles of LDS latency in front of every 96 cycles of matrix work, 36 times per wave).  A
@@ -1648,6 +1796,27 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
     };
     sweep(0, 4);
     if (wave + 16 < 18) sweep(4, 5);   // wave-uniform
+#else
+#pragma unroll
+    for (int i = 0; i < kHdSteps; ++i) {
+      const int st = wave + 4 * i;
+      if (st < 18) {   // wave-uniform
+        const int tap = st >> 1, ti = (tap * 11) >> 5, tj = tap - 3 * ti;
+        const int koff = fbase + (ti * kFhFW + tj) * kFhCSF + (st & 1) * 32;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const f16x8 xh = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF));
+          const f16x8 xl = *reinterpret_cast<const f16x8*>(F + koff + r * (kFhFW * kFhCSF) + 64);
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) {
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwl[i][t], xh, acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xl, acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hwh[i][t], xh, acc[r][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+#endif
     stamp(6);
     // partial sums -> LDS [wave][row][tile][lane] (F and U are dead once every wave is here)
     f32x4* part = reinterpret_cast<f32x4*>(smem_raw);
@@ -1675,6 +1844,7 @@ __global__ __launch_bounds__(256, 2) void fire_head_kernel(const FireHeadArgs a)
   if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
 
+#ifdef PCLSEG_CAND_WIDE
 // ---- Wide 1x1 convolutions (Darknet's BasicBlock / decoder-block conv1: 128-1024 -> 64-1024 channels), split-f16.
 // Reference: nets/Darknet.py:34-43 (conv1 1x1 + bn1 + LeakyReLU of BasicBlock).
 // conv_kernel runs them as `stage a 64-channel chunk -> barrier -> 2 K-steps -> barrier`: a chunk's matrix work is
@@ -1860,6 +2030,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wide_kernel(const ConvArgs a) 
   }
   if (vmax >= kF16Max && a.range_flag) atomicOr(a.range_flag, 1u);
 }
+#endif  // PCLSEG_CAND_WIDE
 
 // ---- 1x1 convolutions without LDS (split-f16 mode).
 // A 1x1 conv has no halo, so staging its input through LDS only buys the hi/lo split and costs two
@@ -2368,6 +2539,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
 #pragma unroll
   for (int nn = 0; nn < (SQ > 0 ? SQ : 1); ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float vmax = 0.f;
+#ifdef PCLSEG_CAND_CAM
   // fused squeeze: a chunk's weight fragments are requested one gate pass AHEAD of their MFMAs (they were fetched
   // right in front of them: NCH * CK/32 exposed L2 round trips per block, in a kernel whose blocks are short
   // chains of dependent phases; all chunks at once costs 16 more registers than the 128 this kernel may use)
@@ -2384,6 +2556,7 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
       }
   };
   if constexpr (SQ > 0) load_sqw(0);
+#endif
 #pragma unroll
   for (int chunk = 0; chunk < NCH; ++chunk) {
     if (active) {
@@ -2432,20 +2605,32 @@ __global__ __launch_bounds__(8 * CK, 4) void cam_kernel(const CamArgs a) {
         for (int t = 0; t < CK / 32; ++t) {
           const f16x8 xh = *reinterpret_cast<const f16x8*>(xrow + t * 32);
           const f16x8 xl = *reinterpret_cast<const f16x8*>(xrow + t * 32 + CK);
+#ifdef PCLSEG_CAND_CAM
 #pragma unroll
           for (int nn = 0; nn < SQ; ++nn) {
             const f16x8 wh = swh[t][nn], wl = swl[t][nn];
+#else
+          const _Float16* wp = a.sq_w16 + ((size_t)(chunk * (CK / 32) + t) * SQ) * 1024 + lane * 8;
+#pragma unroll
+          for (int nn = 0; nn < SQ; ++nn) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + nn * 1024);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + nn * 1024 + 512);
+#endif
             acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[nn], 0, 0, 0);
             acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[nn], 0, 0, 0);
             acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[nn], 0, 0, 0);
           }
         }
       }
+#ifdef PCLSEG_CAND_CAM
       if (chunk + 1 < NCH) {
         asm volatile("" ::: "memory");   // (the next chunk's fragments: requested AFTER this chunk's MFMAs have read theirs)
         load_sqw(chunk + 1);
         lds_barrier();                   // (orders LDS only: a __syncthreads() would drain vmcnt and wait for the request right here)
       }
+#else
+      if (chunk + 1 < NCH) __syncthreads();
+#endif
     }
   }
   if constexpr (SQ > 0) {

@@ -216,8 +216,10 @@ def gather_predictions(local_preds, n_total, dst=0):
   pad = torch.zeros((max_n,) + tuple(local_preds.shape[1:]), dtype=local_preds.dtype,
                     device=local_preds.device)
   pad[:local_preds.shape[0]] = local_preds
-  bufs = [torch.empty_like(pad) for _ in range(world)]
-  dist.all_gather(bufs, pad)
+  # gather, not all_gather: only `dst` receives (and allocates) the other ranks' 16.8 MB shards (C4: 32 scans of
+  # 64x2048 int32 per GPU) — 1/world of the xGMI traffic of handing every shard to every rank
+  bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+  dist.gather(pad, gather_list=bufs, dst=dst)
   if rank != dst:
     return None
   return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, counts)], dim=0)

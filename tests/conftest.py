@@ -17,13 +17,17 @@ if SIM:
 def pytest_configure(config):
   config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
   config.addinivalue_line("markers", "first_hw_run: not yet run on an MI355X (GPU access closed since it was written): ordered last")
+  config.addinivalue_line("markers", "sim: CPU-suite test that runs a slice of the GPU suite / the race driver on the functional simulator (minutes each): "
+                                     "ordered last, deselect with -m 'not gpu and not sim'")
   config.addinivalue_line("markers", "needs_hip: uses torch.cuda / RCCL / the HIP runtime itself; skipped in simulator mode")
 
 
 def pytest_collection_modifyitems(config, items):
   # tests that have not yet passed once on an MI355X run LAST: the driver uses `pytest -x`, and a first-run surprise
   # in a new test must not hide the verified suite behind it (they are ordinary strict tests, never xfail)
-  items.sort(key=lambda it: "first_hw_run" in it.keywords)
+  # (and the slow simulator slices of the CPU suite run after the fast host tests, so a failure or a time budget there
+  # cannot hide them)
+  items.sort(key=lambda it: ("first_hw_run" in it.keywords, "sim" in it.keywords))
   if SIM:
     skip = pytest.mark.skip(reason="simulator mode: needs the real HIP runtime")
     for it in items:

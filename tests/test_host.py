@@ -263,7 +263,10 @@ def test_plan_ops_lists_every_launch_with_its_macs(arch, cfg, h, w):
     assert 0 <= lds <= 160 * 1024 and threads in (256, 512) and blocks >= 1, (name, lds, threads, blocks)
   if arch == "squeezesegv2":
     by = {r[0]: r for r in res}
-    assert by["fire8/expand+fire9/squeeze"][2:] == (73728, 512, 128)       # 72 KB (partial-sum slab in two passes): two blocks fit a CU
+    # shipped kernels: fire8/9's 136 KB partial-sum slab (one block per CU); the candidate build (make candidates,
+    # -DPCLSEG_CAND_SLAB, not yet run on an MI355X) passes it through LDS in two halves: 72 KB, two blocks fit a CU
+    slab = by["fire8/expand+fire9/squeeze"][2:]
+    assert slab == (139264, 512, 128) or (E.DEBUG_LIB and slab == (73728, 512, 128)), slab
     assert by["up+fire13/expand+conv14+head"][2:] == (71424, 256, 1024)    # two 70 KB blocks per CU
     assert by["conv1"][4] == 512 and by["cam1"][3] == 512
 

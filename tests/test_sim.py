@@ -14,6 +14,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.sim      # ordered last by conftest.py; `-m "not gpu and not sim"` is the fast host suite
 
 
 def _sim_pytest(args, timeout, **extra_env):
