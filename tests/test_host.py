@@ -325,3 +325,33 @@ def test_binary_carries_the_hash_of_the_sources_it_was_built_from():
   spec.loader.exec_module(bench)
   assert re.fullmatch(r"[0-9a-f]{16}", E.build_sha()), E.build_sha()
   assert E.build_sha() == bench.csrc_sha()
+
+
+def test_shipped_kernels_are_the_set_verified_on_an_mi355x():
+  """The last hardware run of this repository's kernels was round 3's (GPUTEST_r03 / BENCH_r03: 127 tests green,
+  6 549 scans/s).  Until an MI355X runs the suite again, the library that SHIPS (plain `make`) may only contain device
+  kernels whose instruction streams are those of that tree: tests/golden/verified_kernels_r03.json holds a hash of
+  every kernel's gfx950 instructions (scripts/kernel_isa_diff.py --write-manifest ad2e081).  Instantiations may be
+  dropped (dispatch tables cut to what a plan selects), none may change or appear.  Kernel work that has not met the
+  hardware lives behind -DPCLSEG_CAND (`make candidates`); this test is what keeps it there.  When a GPU run has
+  verified a new kernel set, regenerate the manifest from that commit."""
+  import importlib.util
+  import shutil
+  if not shutil.which("/opt/rocm/bin/hipcc"):
+    pytest.skip("needs hipcc")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location("kernel_isa_diff", os.path.join(root, "scripts", "kernel_isa_diff.py"))
+  kid = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(kid)
+  want = json.load(open(os.path.join(root, "tests", "golden", "verified_kernels_r03.json")))
+  hipcc = kid.subprocess.check_output([kid.HIPCC[0], "--version"], text=True).splitlines()[0]
+  if hipcc != want["hipcc"]:
+    pytest.skip("manifest was written with %s, this is %s" % (want["hipcc"], hipcc))
+  have = kid.manifest_of_tree()
+  assert len(have) >= 100
+  new = sorted(k for k in have if k not in want["kernels"])
+  changed = sorted(k for k in have if k in want["kernels"] and have[k] != want["kernels"][k])
+  assert not new and not changed, "kernels that never ran on an MI355X in the shipped build: new %s changed %s" % (new[:3], changed[:3])
+  # and the candidate switch really changes kernels (the manifest check is not vacuous)
+  cand = kid.manifest_of_tree(["-DPCLSEG_CAND"])
+  assert any(k not in want["kernels"] or cand[k] != want["kernels"][k] for k in cand)
