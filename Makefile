@@ -19,7 +19,7 @@ $(LIB): $(SRCS)
 	$(call hipbuild,$@,$(EXTRA))
 
 # the candidate kernel variants of pclseg_kernels.h (never run on an MI355X; NOT in the shipped library): the
-# hardware A/B of scripts/gpu_step2.sh loads this one through PCLSEG_DEBUG=1 PCLSEG_LIB=build/libpclseg_cand.so
+# hardware A/B of scripts/gpu_all.sh (step 4) loads this one through PCLSEG_DEBUG=1 PCLSEG_LIB=build/libpclseg_cand.so
 candidates: $(SRCS)
 	@mkdir -p build
 	$(call hipbuild,build/libpclseg_cand.so,-DPCLSEG_CAND $(EXTRA))

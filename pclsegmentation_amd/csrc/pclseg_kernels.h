@@ -33,7 +33,7 @@
 // but never run on an MI355X — the shipped library (plain `make`) does not contain them: its device kernels are
 // instruction-identical to the set round 3 verified and measured on hardware (scripts/kernel_isa_diff.py ad2e081).
 // `make candidates` (-DPCLSEG_CAND) builds build/libpclseg_cand.so with all of them for the hardware A/B of
-// scripts/gpu_step2.sh; each has its own switch for per-component builds (make variant NAME=tail EXTRA=-DPCLSEG_CAND_TAIL).
+// scripts/gpu_all.sh; each has its own switch for per-component builds (make variant NAME=tail EXTRA=-DPCLSEG_CAND_TAIL).
 // A candidate moves out of this block (and its #else branch is deleted) only when it is bit-identical AND not slower
 // on the device.
 #ifdef PCLSEG_CAND

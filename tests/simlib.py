@@ -1,6 +1,7 @@
 """Functional-simulator mode of the GPU suite (test infrastructure, like oracle/).
 
     PCLSEG_SIM=1 python -m pytest tests -m gpu          # the GPU tests on sim/_build/libpclseg_sim.so
+    PCLSEG_SIM=cand ...                                  # the candidate kernel variants (make candidates; -DPCLSEG_CAND)
     PCLSEG_SIM=asan ...                                  # AddressSanitizer build (needs LD_PRELOAD, see sim/Makefile)
 
 sim/ compiles the UNMODIFIED sources of pclsegmentation_amd/csrc for x86-64 against a stand-in <hip/hip_runtime.h>
@@ -16,7 +17,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_DIR = os.path.join(ROOT, "sim")
-TARGETS = {"1": ("all", "libpclseg_sim.so"), "asan": ("asan", "libpclseg_sim_asan.so"), "ubsan": ("ubsan", "libpclseg_sim_ubsan.so"),
+TARGETS = {"1": ("all", "libpclseg_sim.so"), "cand": ("cand", "libpclseg_sim_cand.so"), "asan": ("asan", "libpclseg_sim_asan.so"), "ubsan": ("ubsan", "libpclseg_sim_ubsan.so"),
            "traffic": ("traffic", "libpclseg_sim_traffic.so")}
 
 

@@ -327,6 +327,20 @@ def test_binary_carries_the_hash_of_the_sources_it_was_built_from():
   assert E.build_sha() == bench.csrc_sha()
 
 
+def test_committed_traffic_figure_belongs_to_these_sources():
+  """bench.py quotes roofline.traffic from the newest profiles/rNN_traffic.json only when its csrc sha is the loaded
+  library's (attach_traffic); a source edit without `scripts/carry_traffic.py` (kernels unchanged) or a re-measurement
+  (kernels changed) would silently turn the field into null on the next bench line."""
+  import importlib.util
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(root, "bench.py"))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  t = json.load(open(bench._latest_traffic_json()))
+  assert t["csrc_sha"] == bench.csrc_sha(), (bench._latest_traffic_json(), t["csrc_sha"], bench.csrc_sha())
+  assert set(t["workloads"]) >= {"ssv2_64x2048", "darknet53_64x2048", "darknet21_32x1024"}
+
+
 def test_shipped_kernels_are_the_set_verified_on_an_mi355x():
   """The last hardware run of this repository's kernels was round 3's (GPUTEST_r03 / BENCH_r03: 127 tests green,
   6 549 scans/s).  Until an MI355X runs the suite again, the library that SHIPS (plain `make`) may only contain device
