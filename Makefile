@@ -40,8 +40,13 @@ variant: $(SRCS)
 	@mkdir -p build
 	$(call hipbuild,build/libpclseg_$(NAME).so,$(EXTRA))
 
+# after a host-only source edit: re-key round 3's measured PMC traffic to the new source hash (refused by the script if any
+# shipped device kernel differs from the measured build; tests/test_host.py checks file and sources agree)
+carry: all
+	python3 scripts/carry_traffic.py profiles/r03_traffic.json ad2e081 profiles/r06_traffic.json $(wildcard profiles/r03_*_kernel_stats.csv)
+
 clean:
 	rm -f $(LIB) pclsegmentation_amd/libpclseg_*.so
 	rm -rf build sim/_build
 
-.PHONY: all clean stamps tuning variant candidates
+.PHONY: all clean stamps tuning variant candidates carry
