@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 R=${1:-r06}; QUICK=$2
 O=gpurun_out/$R
 mkdir -p $O
+make -s all candidates > $O/make.log 2>&1 || tail -5 $O/make.log     # (no-op when the libraries that travelled are current)
 CAND=$PWD/build/libpclseg_cand.so
 WLS="ssv2_64x2048 darknet53_64x2048 darknet21_32x1024"
 rocminfo 2>/dev/null | grep -m1 gfx9 > $O/device.txt; rocm-smi --showclocks 2>/dev/null | head -20 >> $O/device.txt
