@@ -15,14 +15,15 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["pclsegmentation_amd/csrc/pclseg_kernels.h", "pclsegmentation_amd/csrc/pclseg_api.hip",
          "pclsegmentation_amd/csrc/pclseg_graph.h", "include/pclseg.h"]
-HIPCC = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-function", "-save-temps"]
+# the device side only, as assembly (the Makefile's flags; the host compile adds nothing to compare)
+HIPCC = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function", "--cuda-device-only", "-S"]
 
 
 def build(src_root, out_dir, extra):
   os.makedirs(out_dir, exist_ok=True)
-  subprocess.check_call(HIPCC + extra + ["-o", "lib.so", os.path.join(src_root, FILES[1])], cwd=out_dir,
+  subprocess.check_call(HIPCC + extra + ["-o", "device.s", os.path.join(src_root, FILES[1])], cwd=out_dir,
                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-  return os.path.join(out_dir, "pclseg_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+  return os.path.join(out_dir, "device.s")
 
 
 def kernels(path):
