@@ -121,7 +121,18 @@ def _conv2d_case(cuda, case, math):
   got = y.cpu().numpy()
   assert np.isfinite(got).all(), "kernel left outputs unwritten"
   err = np.abs(got - y64).max()
-  assert err <= 2e-5 * max(1.0, np.abs(y64).max()), err
+  tol = 2e-5 * max(1.0, np.abs(y64).max())
+  _log_margin("conv2d", case, math, err, tol)
+  assert err <= tol, err
+
+
+def _log_margin(kind, case, math, err, tol):
+  """PCLSEG_TOL_LOG=<file>: one line per case with err / tol (how much of the tolerance a build uses; scripts/tol_margin.py)."""
+  import os
+  path = os.environ.get("PCLSEG_TOL_LOG")
+  if path:
+    with open(path, "a") as fh:
+      fh.write("%s\t%s\t%s\t%.3e\t%.3e\t%.4f\n" % (kind, "x".join(str(v) for v in case), math, err, tol, err / tol))
 
 
 def _fuzz_cases(count, seed):
@@ -149,7 +160,15 @@ def _fuzz_cases(count, seed):
 def test_conv2d_fuzz(cuda, case, math):
   """Every shape is either computed to the oracle's values or rejected with a shape error — never wrong, never a
   crash, never a partly written output (the kernels behind the operator entry point are picked by a dispatch table
-  of tile shapes and epilogues of which the three networks use a fraction)."""
+  of tile shapes and epilogues of which the three networks use a fraction).
+
+  Tolerance (verdict r5 #8).  2e-5 x max(1, max|y|) is not a calibration on a few hardware cases: with K = k*k*cin products per
+  output, float32 accumulation contributes about sqrt(R) x 2^-24 x |y| (R = roundings of the accumulator: K in exact mode and on
+  the simulator, which rounds after every k; at most 3 K / 32 block sums on the device's f16 MFMA), i.e. <= 6e-6 |y| (1 sigma) at
+  the largest K here (9216); the dropped lo x lo term and the activation split (absolute 2^-25 below 1/8) are two orders
+  smaller.  Measured on the simulator's pessimistic rounding order the worst of the 448 convolution cases uses 34 % of the
+  tolerance (profiles/r06_sim_tolerance_margin.txt, K = 9216); the 16 cases round 3 ran on an MI355X passed with the same
+  bound."""
   try:
     _conv2d_case(cuda, case, math)
   except ValueError as e:
@@ -219,7 +238,9 @@ def _conv2d_transpose_case(cuda, case, math):
   E.op_conv2d_transpose(dev(x, cuda), n, h, w, cin, kern, bias, bn, act, y, math)
   got = y.cpu().numpy()
   assert np.isfinite(got).all()
-  assert np.abs(got - y64).max() <= 2e-5 * max(1.0, np.abs(y64).max())
+  err, tol = np.abs(got - y64).max(), 2e-5 * max(1.0, np.abs(y64).max())
+  _log_margin("conv2d_transpose", case, math, err, tol)
+  assert err <= tol, err
 
 
 def test_conv2d_transpose_impulse_known_answer(cuda):
