@@ -68,6 +68,8 @@ def sync_device():
 
 
 _HOST = []     # (first byte, one past the last, pinned?) of every tensor host_tensor() handed out; views of them count
+_KEEP = []     # the tensors themselves: a freed one's address would be handed to a later "device" tensor, which _host_range
+               # would then call host memory (seen as a load-dependent failure of whichever test allocated next)
 
 
 def _host_range(ptr):
@@ -93,4 +95,5 @@ def host_tensor(shape, dtype, pinned):
     buf = (ctypes.c_uint8 * nbytes).from_address(p)     # (never freed: a test process)
     t = torch.from_numpy(np.frombuffer(buf, dtype=np.uint8)).view(dtype)[:t.numel()].view(shape)
   _HOST.append((t.data_ptr(), t.data_ptr() + max(1, t.numel() * t.element_size()), bool(pinned)))
+  _KEEP.append(t)
   return t
