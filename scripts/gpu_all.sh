@@ -41,7 +41,9 @@ if [ -f $CAND ]; then
     done
   done > $O/ab.log 2>&1
   cat $O/ab.log
-  # one lane, per operator: which candidate pays where (both libraries, same box)
+  # one lane, per OPERATOR (launch position in the micro-batch), SqueezeSegV2: shipped | candidates | shipped | candidates
+  timeout 900 bash scripts/ab_prof.sh "" "PCLSEG_DEBUG=1 PCLSEG_LIB=$CAND" "" "PCLSEG_DEBUG=1 PCLSEG_LIB=$CAND" > $O/ab_per_op_ssv2.txt 2>&1; tail -26 $O/ab_per_op_ssv2.txt
+  # one lane, per KERNEL: which candidate pays where (both libraries, same box)
   for lib in "" "$CAND"; do
     tag=shipped; [ -n "$lib" ] && tag=cand
     ( [ -n "$lib" ] && export PCLSEG_DEBUG=1 PCLSEG_LIB=$lib
